@@ -1,0 +1,37 @@
+// mhx_device_consts.h -- geometry and flag constants shared by kernels, host engine and
+// the CPU phase emulator (no HIP headers needed).
+#pragma once
+#include <stdint.h>
+
+namespace mhx {
+
+// ---- tile geometry of the sketch kernel ------------------------------------------------
+constexpr int kTileBytes = 32768;                    // bytes of the stream one workgroup owns
+constexpr int kHaloBytes = 64;                       // staged beyond the tile (>= 8 + 32)
+constexpr int kBlock = 256;                          // threads per workgroup (4 waves)
+constexpr int kGroup = 8;                            // k-mer start positions per work item
+constexpr int kGroupsPerTile = kTileBytes / kGroup;  // 4096
+constexpr int kBytesPerThread = kTileBytes / kBlock; // 128
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // vacant slot of the candidate table
+
+// device flag bits (stats[kStatFlags])
+constexpr uint64_t kFlagTableFull = 1;   // probe limit hit: result not exact, retry bigger
+constexpr uint64_t kFlagBadFastq = 2;    // a record violated the 4-line layout
+constexpr uint64_t kFlagSpinTimeout = 4; // look-back spin bound hit (should never happen)
+
+enum Stat : int {
+    kStatKmers = 0,   // valid windows hashed
+    kStatInserts = 1, // occurrences admitted (hash <= threshold)
+    kStatLines = 2,   // newline count of the FASTQ stream
+    kStatFlags = 3,
+    kStatMaxKey = 4,  // occurrences of the hash value 2^64-1 (cannot live in the table)
+    kStatOccupied = 5,
+    kStatSolid = 6,   // entries <= T with count >= m seen by the last tighten pass
+    kStatCount = 8
+};
+constexpr int kStatReplicas = 64; // counters are replicated to spread atomic traffic
+
+constexpr int kHistBins = 2048;
+
+} // namespace mhx

@@ -1,0 +1,853 @@
+// mhx_engine.cpp -- host side of libmhx: device selection, the sketcher object that
+// schedules tile launches and threshold tightening, the batched distance entry point and
+// the two file-level calls that replace AuriClass's `mash sketch` / `mash dist`
+// subprocesses (/root/reference/auriclass/classes.py:576-596, 696-713, 92-104).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "mhx_device.h"
+#include "mhx_internal.h"
+
+namespace mhx {
+
+// ---- errors ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+int fail(int code, const char *fmt, ...)
+{
+    char b[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof(b), fmt, ap);
+    va_end(ap);
+    g_err = b;
+    return code;
+}
+void clear_error() { g_err.clear(); }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MHX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- engine state ---------------------------------------------------------------------
+struct Engine {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_dist_ms = 0.0;
+};
+static Engine g;
+
+static int require_engine()
+{
+    if (!g.ready) return fail(MHX_E_NO_DEVICE, "mhx: no GPU engine (call mhx_init on a machine with a HIP device; there is no CPU fallback)");
+    return MHX_OK;
+}
+
+} // namespace mhx
+
+using namespace mhx;
+
+extern "C" const char *mhx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *mhx_version(void) { return "mhx 0.1.0 (gfx950)"; }
+extern "C" void *mhx_stream(void) { return g.stream; }
+
+extern "C" int mhx_init(int device)
+{
+    clear_error();
+    if (g.ready && (device < 0 || device == g.device)) return MHX_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MHX_E_NO_DEVICE, "mhx: no HIP device visible (MI355X required; there is no CPU fallback)");
+    if (device < 0) device = 0;
+    if (device >= n) return fail(MHX_E_ARG, "mhx_init: device %d out of range (%d visible)", device, n);
+    if (g.ready) mhx_shutdown();
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&g.ev0));
+    HIPCHK(hipEventCreate(&g.ev1));
+    g.device = device;
+    g.ready = true;
+    return MHX_OK;
+}
+
+extern "C" void mhx_shutdown(void)
+{
+    if (!g.ready) return;
+    hipStreamSynchronize(g.stream);
+    hipEventDestroy(g.ev0);
+    hipEventDestroy(g.ev1);
+    hipStreamDestroy(g.stream);
+    g = Engine();
+}
+
+extern "C" int mhx_device_name(char *buf, size_t cap)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, g.device));
+    snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MHX_OK;
+}
+
+extern "C" int mhx_set_profiling(int on)
+{
+    g.profiling = on != 0;
+    return MHX_OK;
+}
+
+// ---- sketcher -------------------------------------------------------------------------
+struct mhx_sketcher {
+    int k = 0;
+    uint32_t s = 0, m = 1;
+    bool hash32 = false;
+    uint64_t nslots = 0;
+    uint64_t hash_max = 0;   // largest representable hash (2^64-1 or 2^32-1)
+    uint64_t t_init = 0;     // initial admission threshold
+    // device
+    uint64_t *d_keys = nullptr;
+    uint32_t *d_cnts = nullptr;
+    uint64_t *d_thresh = nullptr;
+    uint32_t *d_hist = nullptr;
+    uint64_t *d_acc = nullptr;
+    uint64_t *d_stats = nullptr;   // kStatReplicas x kStatCount
+    uint32_t *d_tickets = nullptr; // one per launch of a push
+    uint64_t *d_tile_state = nullptr;
+    size_t tile_state_cap = 0;
+    uint8_t *d_stage = nullptr;
+    size_t stage_cap = 0;
+    uint64_t *d_out_keys = nullptr;
+    uint32_t *d_out_cnts = nullptr;
+    uint32_t *d_out_n = nullptr;
+    uint32_t out_cap = 0;
+    // host
+    uint64_t next_chunk_bytes = 0; // geometric schedule of the tightening phase
+    bool settled = false;          // threshold tight enough: remaining data goes in one launch
+    uint64_t bytes_pushed = 0;
+    uint64_t expected_bytes = 0;
+    double hash_ms = 0.0;
+    uint64_t launches = 0;
+    uint64_t last_T = 0;
+};
+
+static constexpr int kMaxLaunchesPerPush = 64;
+
+static TableArgs table_args(mhx_sketcher *sk)
+{
+    TableArgs t;
+    t.keys = sk->d_keys; t.cnts = sk->d_cnts; t.nslots = sk->nslots; t.thresh = sk->d_thresh;
+    t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.min_mult = sk->m; t.sketch_size = sk->s;
+    return t;
+}
+
+static void free_sketcher(mhx_sketcher *sk)
+{
+    if (!sk) return;
+    hipFree(sk->d_keys); hipFree(sk->d_cnts); hipFree(sk->d_thresh); hipFree(sk->d_hist); hipFree(sk->d_acc);
+    hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
+    hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
+    delete sk;
+}
+
+static uint64_t next_pow2(uint64_t v)
+{
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk) return fail(MHX_E_ARG, "null sketcher");
+    HIPCHK(hipMemsetAsync(sk->d_keys, 0xFF, sk->nslots * sizeof(uint64_t), g.stream));
+    HIPCHK(hipMemsetAsync(sk->d_cnts, 0, sk->nslots * sizeof(uint32_t), g.stream));
+    HIPCHK(hipMemsetAsync(sk->d_hist, 0, kHistBins * sizeof(uint32_t), g.stream));
+    HIPCHK(hipMemsetAsync(sk->d_acc, 0, 2 * sizeof(uint64_t), g.stream));
+    HIPCHK(hipMemsetAsync(sk->d_stats, 0, kStatReplicas * kStatCount * sizeof(uint64_t), g.stream));
+    // Admission threshold.  With everything admitted the table must be able to hold every
+    // distinct k-mer of the first chunk; for larger inputs start from the occurrence bound
+    // (at most nslots/4 admissions over the whole expected input).  finish() verifies that
+    // the bound was loose enough and reports MHX_E_CAPACITY otherwise.
+    uint64_t T = sk->hash_max;
+    if (sk->m > 1 && sk->expected_bytes > sk->nslots / 4) {
+        const long double frac = (long double)(sk->nslots / 4) / (long double)sk->expected_bytes;
+        T = (uint64_t)(frac * (long double)sk->hash_max);
+    }
+    sk->t_init = T;
+    sk->last_T = T;
+    HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); // t_init is a host stack-free member, but keep reset synchronous
+    uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
+    if (c0 < (256u << 10)) c0 = 256u << 10;
+    if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
+    sk->next_chunk_bytes = c0;
+    sk->settled = false;
+    sk->bytes_pushed = 0;
+    sk->hash_ms = 0.0;
+    sk->launches = 0;
+    return MHX_OK;
+}
+
+static int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint64_t table_scale, mhx_sketcher **out)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!out) return fail(MHX_E_ARG, "null out pointer");
+    if (!hash_k_supported(k)) return fail(MHX_E_ARG, "k-mer size %d not supported (1..32)", k);
+    if (s == 0) return fail(MHX_E_ARG, "sketch size must be positive");
+    mhx_sketcher *sk = new mhx_sketcher();
+    sk->k = k; sk->s = s; sk->m = min_mult ? min_mult : 1;
+    sk->hash32 = k <= 16;
+    sk->hash_max = sk->hash32 ? 0xFFFFFFFFull : ~0ull;
+    sk->expected_bytes = expected_bytes;
+    // table: >= 2^22 slots, >= 1024 slots per sketch entry when a multiplicity filter makes
+    // early tightening impossible (coverage up to ~256x stays exact in one pass), else 256
+    uint64_t want = (uint64_t)s * (sk->m > 1 ? 1024 : 256);
+    if (want < (1ull << 22)) want = 1ull << 22;
+    if (expected_bytes && expected_bytes * 4 < want && expected_bytes * 4 >= (1ull << 16)) want = expected_bytes * 4;
+    if (expected_bytes && expected_bytes * 4 < (1ull << 16)) want = 1ull << 16;
+    want *= table_scale;
+    if (want > (1ull << 30)) want = 1ull << 30; // 12.9 GB of table at most
+    sk->nslots = next_pow2(want);
+    sk->out_cap = s * 2 + 65536;
+    hipError_t e = hipSuccess;
+    auto A = [&](void **p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
+    A((void **)&sk->d_keys, sk->nslots * sizeof(uint64_t));
+    A((void **)&sk->d_cnts, sk->nslots * sizeof(uint32_t));
+    A((void **)&sk->d_thresh, sizeof(uint64_t));
+    A((void **)&sk->d_hist, kHistBins * sizeof(uint32_t));
+    A((void **)&sk->d_acc, 2 * sizeof(uint64_t));
+    A((void **)&sk->d_stats, kStatReplicas * kStatCount * sizeof(uint64_t));
+    A((void **)&sk->d_tickets, kMaxLaunchesPerPush * sizeof(uint32_t));
+    A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));
+    A((void **)&sk->d_out_cnts, sk->out_cap * sizeof(uint32_t));
+    A((void **)&sk->d_out_n, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        free_sketcher(sk);
+        return fail(MHX_E_HIP, "hipMalloc failed while creating the sketcher: %s", hipGetErrorString(e));
+    }
+    rc = mhx_sketcher_reset(sk);
+    if (rc) { free_sketcher(sk); return rc; }
+    *out = sk;
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_create(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, mhx_sketcher **out)
+{
+    return create_sketcher(k, s, min_mult, expected_bytes, 1, out);
+}
+
+extern "C" void mhx_sketcher_destroy(mhx_sketcher *sk)
+{
+    if (g.ready) hipStreamSynchronize(g.stream);
+    free_sketcher(sk);
+}
+
+static int read_threshold(mhx_sketcher *sk, uint64_t *T)
+{
+    HIPCHK(hipMemcpyAsync(T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    sk->last_T = *T;
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int fmt)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || (!d_bytes && n)) return fail(MHX_E_ARG, "null argument");
+    if (fmt != MHX_FMT_SEQ && fmt != MHX_FMT_FASTQ4) return fail(MHX_E_ARG, "unknown stream format %d", fmt);
+    if (n == 0) return MHX_OK;
+    const uintptr_t p = (uintptr_t)d_bytes;
+    const uintptr_t base = p & ~(uintptr_t)15;
+    HashArgs a;
+    a.base = (const uint8_t *)base;
+    a.begin = p - base;
+    a.end = a.begin + n;
+    a.first_tile = 0;
+    a.hash32 = sk->hash32 ? 1 : 0;
+    a.thresh = sk->d_thresh;
+    a.keys = sk->d_keys; a.cnts = sk->d_cnts; a.slot_mask = sk->nslots - 1; a.stats = sk->d_stats;
+    const uint64_t ntiles64 = (a.end + kTileBytes - 1) / kTileBytes;
+    if (ntiles64 > 0x7FFFFFFFull) return fail(MHX_E_ARG, "span too large for one push (%llu bytes)", (unsigned long long)n);
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    if (fmt == MHX_FMT_FASTQ4) {
+        if (sk->tile_state_cap < ntiles) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            hipFree(sk->d_tile_state);
+            sk->d_tile_state = nullptr;
+            sk->tile_state_cap = 0;
+            HIPCHK(hipMalloc((void **)&sk->d_tile_state, (size_t)ntiles * sizeof(uint64_t)));
+            sk->tile_state_cap = ntiles;
+        }
+        HIPCHK(hipMemsetAsync(sk->d_tile_state, 0, (size_t)ntiles * sizeof(uint64_t), g.stream));
+        HIPCHK(hipMemsetAsync(sk->d_tickets, 0, kMaxLaunchesPerPush * sizeof(uint32_t), g.stream));
+    }
+    a.tile_state = sk->d_tile_state;
+    const TableArgs ta = table_args(sk);
+    uint32_t tile = 0;
+    int launch = 0;
+    while (tile < ntiles) {
+        uint32_t take = ntiles - tile;
+        const bool last_slot = launch == kMaxLaunchesPerPush - 1;
+        if (!sk->settled && !last_slot) {
+            const uint64_t chunk_tiles = (sk->next_chunk_bytes + kTileBytes - 1) / kTileBytes;
+            if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
+        }
+        a.tile0 = tile;
+        a.ntiles = take;
+        a.ticket = sk->d_tickets + launch;
+        if (g.profiling) HIPCHK(hipEventRecord(g.ev0, g.stream));
+        HIPCHK(launch_hash(sk->k, fmt, a, g.stream));
+        if (g.profiling) {
+            HIPCHK(hipEventRecord(g.ev1, g.stream));
+            HIPCHK(hipEventSynchronize(g.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+            sk->hash_ms += ms;
+        }
+        ++sk->launches;
+        ++launch;
+        tile += take;
+        sk->bytes_pushed += (uint64_t)take * kTileBytes;
+        if (!sk->settled) {
+            // tighten T from what has been seen, then decide whether the rest can go at once:
+            // expected admissions of everything still to come must fit an eighth of the table
+            HIPCHK(launch_tighten(ta, g.stream));
+            uint64_t T;
+            rc = read_threshold(sk, &T);
+            if (rc) return rc;
+            const uint64_t total = sk->expected_bytes > sk->bytes_pushed ? sk->expected_bytes : (uint64_t)ntiles * kTileBytes;
+            const uint64_t remaining = total > sk->bytes_pushed ? total - sk->bytes_pushed : (uint64_t)(ntiles - tile) * kTileBytes;
+            const long double admit = (long double)remaining * ((long double)T / (long double)sk->hash_max);
+            if (admit <= (long double)(sk->nslots / 8)) sk->settled = true;
+            else sk->next_chunk_bytes *= 4;
+        }
+    }
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_push_host(mhx_sketcher *sk, const void *h_bytes, uint64_t n, int fmt)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || (!h_bytes && n)) return fail(MHX_E_ARG, "null argument");
+    if (n == 0) return MHX_OK;
+    // the staging buffer is reused: wait for earlier pushes that may still read it
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (sk->stage_cap < n + 64) {
+        hipFree(sk->d_stage);
+        sk->d_stage = nullptr;
+        sk->stage_cap = 0;
+        const size_t cap = (size_t)((n + 64 + (1u << 20) - 1) & ~(uint64_t)((1u << 20) - 1));
+        HIPCHK(hipMalloc((void **)&sk->d_stage, cap));
+        sk->stage_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(sk->d_stage, h_bytes, n, hipMemcpyHostToDevice, g.stream));
+    return mhx_sketcher_push_device(sk, sk->d_stage, n, fmt);
+}
+
+extern "C" int mhx_sketcher_sync(mhx_sketcher *sk)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    (void)sk;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return MHX_OK;
+}
+
+static int fetch_stats(mhx_sketcher *sk, uint64_t *sum)
+{
+    std::vector<uint64_t> h(kStatReplicas * kStatCount);
+    HIPCHK(hipMemcpyAsync(h.data(), sk->d_stats, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < kStatCount; ++i) sum[i] = 0;
+    for (int r = 0; r < kStatReplicas; ++r) {
+        sum[kStatKmers] += h[r * kStatCount + kStatKmers];
+        sum[kStatInserts] += h[r * kStatCount + kStatInserts];
+        sum[kStatLines] += h[r * kStatCount + kStatLines];
+        sum[kStatMaxKey] += h[r * kStatCount + kStatMaxKey];
+        sum[kStatFlags] |= h[r * kStatCount + kStatFlags];
+    }
+    sum[kStatOccupied] = h[kStatOccupied];
+    sum[kStatSolid] = h[kStatSolid];
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !stats8) return fail(MHX_E_ARG, "null argument");
+    uint64_t s[kStatCount];
+    rc = fetch_stats(sk, s);
+    if (rc) return rc;
+    stats8[0] = s[kStatKmers];
+    stats8[1] = s[kStatInserts];
+    stats8[2] = s[kStatLines];
+    stats8[3] = s[kStatFlags];
+    stats8[4] = s[kStatOccupied];
+    double ms = sk->hash_ms;
+    memcpy(&stats8[5], &ms, sizeof(double));
+    stats8[6] = sk->launches;
+    stats8[7] = sk->last_T;
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_threshold(mhx_sketcher *sk, uint64_t *threshold)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !threshold) return fail(MHX_E_ARG, "null argument");
+    HIPCHK(launch_tighten(table_args(sk), g.stream));
+    return read_threshold(sk, threshold);
+}
+
+static int check_flags(uint64_t flags)
+{
+    if (flags & kFlagSpinTimeout) return fail(MHX_E_INTERNAL, "device look-back timed out");
+    if (flags & kFlagTableFull) return fail(MHX_E_CAPACITY, "device candidate table overflowed; recreate the sketcher with a larger expected_bytes");
+    if (flags & kFlagBadFastq) return fail(MHX_E_FORMAT, "input is not strict 4-line FASTQ (use the record parser path)");
+    return MHX_OK;
+}
+
+// entries (key <= limit, count >= min_count) -> host vectors, unsorted
+static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipMemsetAsync(sk->d_out_n, 0, sizeof(uint32_t), g.stream));
+        HIPCHK(launch_extract(table_args(sk), limit, min_count, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, g.stream));
+        uint32_t n = 0;
+        HIPCHK(hipMemcpyAsync(&n, sk->d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (n > sk->out_cap) { // grow once and repeat
+            hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts);
+            sk->d_out_keys = nullptr; sk->d_out_cnts = nullptr;
+            sk->out_cap = n + 1024;
+            HIPCHK(hipMalloc((void **)&sk->d_out_keys, (size_t)sk->out_cap * sizeof(uint64_t)));
+            HIPCHK(hipMalloc((void **)&sk->d_out_cnts, (size_t)sk->out_cap * sizeof(uint32_t)));
+            continue;
+        }
+        keys.resize(n);
+        cnts.resize(n);
+        if (n) {
+            HIPCHK(hipMemcpyAsync(keys.data(), sk->d_out_keys, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(cnts.data(), sk->d_out_cnts, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        }
+        return MHX_OK;
+    }
+    return fail(MHX_E_INTERNAL, "extract: output kept growing");
+}
+
+static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
+{
+    std::vector<uint32_t> idx(keys.size());
+    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    std::vector<uint64_t> k2(keys.size());
+    std::vector<uint32_t> c2(keys.size());
+    for (size_t i = 0; i < idx.size(); ++i) { k2[i] = keys[idx[i]]; c2[i] = cnts[idx[i]]; }
+    keys.swap(k2);
+    cnts.swap(c2);
+}
+
+extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !hashes || !n_out) return fail(MHX_E_ARG, "null argument");
+    uint64_t T;
+    HIPCHK(launch_tighten(table_args(sk), g.stream));
+    rc = read_threshold(sk, &T);
+    if (rc) return rc;
+    uint64_t st[kStatCount];
+    rc = fetch_stats(sk, st);
+    if (rc) return rc;
+    rc = check_flags(st[kStatFlags]);
+    if (rc) return rc;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> cnts;
+    rc = extract(sk, T, sk->m, keys, cnts);
+    if (rc) return rc;
+    if (T == ~0ull && st[kStatMaxKey] >= sk->m) { // the one hash value the table cannot hold
+        keys.push_back(~0ull);
+        cnts.push_back((uint32_t)st[kStatMaxKey]);
+    }
+    // exactness: either nothing was ever rejected, or at least s qualifying hashes lie below T
+    if (keys.size() < sk->s && sk->t_init != sk->hash_max)
+        return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries); recreate the sketcher with a larger table",
+                    keys.size(), sk->s);
+    sort_pairs(keys, cnts);
+    const uint32_t n = keys.size() < sk->s ? (uint32_t)keys.size() : sk->s;
+    memcpy(hashes, keys.data(), (size_t)n * sizeof(uint64_t));
+    if (counts) memcpy(counts, cnts.data(), (size_t)n * sizeof(uint32_t));
+    *n_out = n;
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts, uint32_t cap, uint32_t *n_out)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !n_out) return fail(MHX_E_ARG, "null argument");
+    uint64_t st[kStatCount];
+    rc = fetch_stats(sk, st);
+    if (rc) return rc;
+    rc = check_flags(st[kStatFlags]);
+    if (rc) return rc;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> cnts;
+    rc = extract(sk, limit, 1, keys, cnts);
+    if (rc) return rc;
+    if (limit == ~0ull && st[kStatMaxKey]) { keys.push_back(~0ull); cnts.push_back((uint32_t)st[kStatMaxKey]); }
+    *n_out = (uint32_t)keys.size();
+    if (keys.size() > cap) return fail(MHX_E_CAPACITY, "export: %zu entries, buffer holds %u", keys.size(), cap);
+    if (!keys.empty()) {
+        if (!hashes || !counts) return fail(MHX_E_ARG, "null output buffer");
+        sort_pairs(keys, cnts);
+        memcpy(hashes, keys.data(), keys.size() * sizeof(uint64_t));
+        memcpy(counts, cnts.data(), cnts.size() * sizeof(uint32_t));
+    }
+    return MHX_OK;
+}
+
+// Union of shard partials: sum the counts of equal hashes, keep count >= m, first s.
+extern "C" int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s, uint32_t min_mult,
+                                  uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out)
+{
+    clear_error();
+    if ((!hashes || !counts) && n) return fail(MHX_E_ARG, "null input");
+    if (!out_hashes || !n_out) return fail(MHX_E_ARG, "null output");
+    std::vector<uint64_t> idx(n);
+    for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return hashes[a] < hashes[b]; });
+    uint32_t w = 0;
+    const uint32_t m = min_mult ? min_mult : 1;
+    for (uint64_t i = 0; i < n && w < s;) {
+        uint64_t j = i, c = 0;
+        while (j < n && hashes[idx[j]] == hashes[idx[i]]) c += counts[idx[j++]];
+        if (c >= m) {
+            out_hashes[w] = hashes[idx[i]];
+            if (out_counts) out_counts[w] = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+            ++w;
+        }
+        i = j;
+    }
+    *n_out = w;
+    return MHX_OK;
+}
+
+// ---- batched distance ------------------------------------------------------------------
+extern "C" double mhx_last_dist_kernel_ms(void) { return g.last_dist_ms; }
+
+extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r, const uint32_t *r_len,
+                              uint32_t nr, uint32_t stride, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist,
+                              int device_ptrs)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (nq == 0 || nr == 0) return MHX_OK;
+    if (!q || !q_len || !r || !r_len || !common || !denom) return fail(MHX_E_ARG, "null argument");
+    if (k < 1 || k > 32 || s == 0 || stride == 0) return fail(MHX_E_ARG, "bad k / s / stride");
+    const uint64_t pairs = (uint64_t)nq * nr;
+    if (pairs > 0x7FFFFFFFull) return fail(MHX_E_ARG, "too many pairs for one call");
+    DistArgs a;
+    a.nq = nq; a.nr = nr; a.stride = stride; a.s = s; a.k = k;
+    void *dq = nullptr, *dr = nullptr, *dql = nullptr, *drl = nullptr, *dc = nullptr, *dd = nullptr, *dx = nullptr;
+    auto cleanup = [&]() { hipFree(dq); hipFree(dr); hipFree(dql); hipFree(drl); hipFree(dc); hipFree(dd); hipFree(dx); };
+    if (device_ptrs) {
+        a.q = q; a.q_len = q_len; a.r = r; a.r_len = r_len; a.common = common; a.denom = denom; a.dist = dist;
+    } else {
+        for (uint32_t i = 0; i < nq; ++i) if (q_len[i] > stride) return fail(MHX_E_ARG, "q_len[%u] exceeds stride", i);
+        for (uint32_t i = 0; i < nr; ++i) if (r_len[i] > stride) return fail(MHX_E_ARG, "r_len[%u] exceeds stride", i);
+        hipError_t e = hipSuccess;
+        auto A = [&](void **p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
+        A(&dq, (size_t)nq * stride * 8); A(&dr, (size_t)nr * stride * 8); A(&dql, (size_t)nq * 4); A(&drl, (size_t)nr * 4);
+        A(&dc, pairs * 4); A(&dd, pairs * 4);
+        if (e != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "hipMalloc failed in dist_batch: %s", hipGetErrorString(e)); }
+        hipMemcpyAsync(dq, q, (size_t)nq * stride * 8, hipMemcpyHostToDevice, g.stream);
+        hipMemcpyAsync(dr, r, (size_t)nr * stride * 8, hipMemcpyHostToDevice, g.stream);
+        hipMemcpyAsync(dql, q_len, (size_t)nq * 4, hipMemcpyHostToDevice, g.stream);
+        hipMemcpyAsync(drl, r_len, (size_t)nr * 4, hipMemcpyHostToDevice, g.stream);
+        a.q = (const uint64_t *)dq; a.q_len = (const uint32_t *)dql; a.r = (const uint64_t *)dr; a.r_len = (const uint32_t *)drl;
+        a.common = (uint32_t *)dc; a.denom = (uint32_t *)dd; a.dist = nullptr; // distances in host libm below
+    }
+    hipEventRecord(g.ev0, g.stream);
+    hipError_t le = launch_dist_pairs(a, g.stream);
+    hipEventRecord(g.ev1, g.stream);
+    if (le != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le)); }
+    if (!device_ptrs) {
+        hipMemcpyAsync(common, dc, pairs * 4, hipMemcpyDeviceToHost, g.stream);
+        hipMemcpyAsync(denom, dd, pairs * 4, hipMemcpyDeviceToHost, g.stream);
+    }
+    hipError_t se = hipStreamSynchronize(g.stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    g.last_dist_ms = ms;
+    cleanup();
+    if (se != hipSuccess) return fail(MHX_E_HIP, "dist kernel failed: %s", hipGetErrorString(se));
+    if (!device_ptrs && dist) {
+        for (uint64_t i = 0; i < pairs; ++i) {
+            double d;
+            if (common[i] == denom[i]) d = 0.0;
+            else if (common[i] == 0) d = 1.0;
+            else {
+                const double j = (double)common[i] / (double)denom[i];
+                d = -log(2.0 * j / (1.0 + j)) / (double)k;
+                if (d > 1.0) d = 1.0;
+            }
+            dist[i] = d;
+        }
+    }
+    return MHX_OK;
+}
+
+// ---- file level -------------------------------------------------------------------------
+static int put_text(const std::string &t, char *buf, size_t cap, size_t *need)
+{
+    if (need) *need = t.size() + 1;
+    if (cap == 0) return MHX_OK;
+    if (!buf || cap < t.size() + 1) return fail(MHX_E_CAPACITY, "text buffer too small (%zu needed)", t.size() + 1);
+    memcpy(buf, t.c_str(), t.size() + 1);
+    return MHX_OK;
+}
+
+static std::string make_comment(const std::string &name, const std::string &comment, uint64_t count)
+{ // mash sketchFile(): "<name> <comment>", wrapped when several records were counted
+    std::string c = name + " " + comment;
+    if (count > 1) c = "[" + std::to_string(count) + " seqs] " + c + " [...]";
+    return c;
+}
+
+struct Loaded {
+    std::vector<uint8_t> raw;  // inflated file
+    ParsedRecords rec;         // filled when the record parser path is used
+    bool fastq4 = false;
+};
+
+// One reference from one or more inputs on the device.  On a 4-line violation or a too
+// tight admission bound the whole reference is redone (record parser / bigger table).
+static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t s, uint32_t m, bool allow_device_fastq,
+                            std::vector<uint64_t> &hashes, std::vector<uint32_t> &counts, uint64_t *kmers)
+{
+    uint64_t total = 0;
+    for (auto *in : inputs) total += in->raw.size();
+    bool device_fastq = allow_device_fastq;
+    uint64_t boost = 1;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        mhx_sketcher *sk = nullptr;
+        int rc = create_sketcher(k, s, m, total, boost, &sk);
+        if (rc) return rc;
+        for (auto *in : inputs) {
+            if (device_fastq && in->fastq4) {
+                rc = mhx_sketcher_push_host(sk, in->raw.data(), in->raw.size(), MHX_FMT_FASTQ4);
+            } else {
+                if (in->rec.records_seen == 0 && in->rec.seq.empty()) {
+                    rc = parse_fastx(in->raw.data(), in->raw.size(), k, in->rec);
+                    if (rc) break;
+                }
+                rc = mhx_sketcher_push_host(sk, in->rec.seq.data(), in->rec.seq.size(), MHX_FMT_SEQ);
+            }
+            if (rc) break;
+        }
+        uint32_t n = 0;
+        if (!rc) {
+            hashes.resize(s);
+            counts.resize(s);
+            rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
+        }
+        if (!rc && kmers) {
+            uint64_t st[8];
+            rc = mhx_sketcher_stats(sk, st);
+            *kmers = st[0];
+        }
+        mhx_sketcher_destroy(sk);
+        if (rc == MHX_E_FORMAT && device_fastq) { device_fastq = false; continue; }
+        if (rc == MHX_E_CAPACITY) { boost *= 16; continue; }
+        if (rc) return rc;
+        hashes.resize(n);
+        counts.resize(n);
+        return MHX_OK;
+    }
+    return fail(MHX_E_CAPACITY, "could not size the device table for this input");
+}
+
+extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
+                                const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
+                                double *est_genome_size)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!paths || n_paths <= 0 || !out_msh) return fail(MHX_E_ARG, "sketch: paths and output required");
+    if (!hash_k_supported(k)) return fail(MHX_E_ARG, "k-mer size %d not supported (1..32)", k);
+    SketchSet set;
+    set.kmer_size = (uint32_t)k;
+    set.sketch_size = s;
+    std::string err;
+    std::vector<Loaded> loaded(n_paths);
+    auto no_records = [&](const char *p) {
+        err += std::string("ERROR: Did not find fasta records in \"") + p + "\".\n";
+        put_text(err, stderr_buf, stderr_cap, stderr_need);
+        return fail(MHX_E_NO_RECORDS, "ERROR: Did not find fasta records in \"%s\".", p);
+    };
+    if (reads) {
+        std::vector<Loaded *> in;
+        for (int i = 0; i < n_paths; ++i) {
+            rc = read_all_maybe_gz(paths[i], loaded[i].raw);
+            if (rc) return rc;
+            loaded[i].fastq4 = looks_like_fastq4(loaded[i].raw.data(), loaded[i].raw.size());
+            in.push_back(&loaded[i]);
+        }
+        RefSketch ref;
+        uint64_t kmers = 0;
+        rc = sketch_reference(in, k, s, min_mult ? min_mult : 1, true, ref.hashes, ref.counts, &kmers);
+        if (rc) return rc;
+        // name / comment / count: first counted record; count = records seen by the parser,
+        // or lines / 4 when the stream went to the device parser untouched
+        std::string fname, fcomment;
+        uint64_t count = 0;
+        bool any = false;
+        for (auto &l : loaded) {
+            if (l.rec.records_seen || !l.rec.seq.empty()) {
+                if (!any && l.rec.records) { fname = l.rec.first_name; fcomment = l.rec.first_comment; any = true; }
+                count += l.rec.records;
+            } else if (!l.raw.empty()) {
+                uint64_t lines = 0;
+                for (size_t off = 0; off < l.raw.size();) {
+                    const void *p = memchr(l.raw.data() + off, '\n', l.raw.size() - off);
+                    if (!p) { ++lines; break; }
+                    ++lines;
+                    off = (const uint8_t *)p - l.raw.data() + 1;
+                }
+                if (!any) { first_header(l.raw.data(), l.raw.size(), fname, fcomment); any = true; }
+                count += lines / 4;
+            }
+        }
+        if (kmers == 0 && count == 0) return no_records(paths[0]);
+        double set_size = 0.0, mult = 0.0;
+        if (!ref.hashes.empty()) {
+            set_size = pow(2.0, k > 16 ? 64.0 : 32.0) * (double)ref.hashes.size() / (double)ref.hashes.back();
+            uint64_t sum = 0;
+            for (uint32_t c : ref.counts) sum += c;
+            mult = (double)sum / (double)ref.hashes.size();
+        }
+        ref.name = paths[0];
+        ref.comment = make_comment(fname, fcomment, count);
+        ref.length = (uint64_t)set_size;
+        ref.counts.clear(); // mash stores counts only with -M
+        set.refs.push_back(std::move(ref));
+        err += "Estimated genome size: " + fmt_g(set_size) + "\n";
+        err += "Estimated coverage:    " + fmt_g(mult) + "\n";
+        if (est_genome_size) *est_genome_size = set_size;
+    } else {
+        for (int i = 0; i < n_paths; ++i) {
+            err += std::string("Sketching ") + paths[i] + "...\n";
+            rc = read_all_maybe_gz(paths[i], loaded[i].raw);
+            if (rc) return rc;
+            rc = parse_fastx(loaded[i].raw.data(), loaded[i].raw.size(), k, loaded[i].rec);
+            if (rc) return rc;
+            if (loaded[i].rec.records == 0) return no_records(paths[i]);
+            RefSketch ref;
+            std::vector<Loaded *> in{&loaded[i]};
+            rc = sketch_reference(in, k, s, 1, false, ref.hashes, ref.counts, nullptr);
+            if (rc) return rc;
+            ref.counts.clear();
+            ref.name = paths[i];
+            ref.comment = make_comment(loaded[i].rec.first_name, loaded[i].rec.first_comment, loaded[i].rec.records);
+            ref.length = loaded[i].rec.total_length;
+            set.refs.push_back(std::move(ref));
+            loaded[i] = Loaded();
+        }
+        if (est_genome_size) *est_genome_size = 0.0;
+    }
+    err += std::string("Writing to ") + out_msh + "...\n";
+    rc = msh_write_file(out_msh, set);
+    if (rc) return rc;
+    return put_text(err, stderr_buf, stderr_cap, stderr_need);
+}
+
+extern "C" int mhx_dist_files(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!ref_msh || !qry_msh) return fail(MHX_E_ARG, "dist: two sketch paths required");
+    SketchSet R, Q;
+    rc = msh_read_file(ref_msh, R);
+    if (rc) return rc;
+    rc = msh_read_file(qry_msh, Q);
+    if (rc) return rc;
+    if (R.kmer_size != Q.kmer_size)
+        return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different k-mer sizes (%u and %u)", Q.kmer_size, R.kmer_size);
+    if (R.hash_seed != Q.hash_seed) return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different hash seeds");
+    const int k = (int)R.kmer_size;
+    const uint32_t s = R.sketch_size < Q.sketch_size ? R.sketch_size : Q.sketch_size;
+    const uint32_t nr = (uint32_t)R.refs.size(), nq = (uint32_t)Q.refs.size();
+    std::string text;
+    if (nr && nq) {
+        uint32_t stride = 1;
+        for (auto &r : R.refs) stride = std::max<uint32_t>(stride, (uint32_t)r.hashes.size());
+        for (auto &q : Q.refs) stride = std::max<uint32_t>(stride, (uint32_t)q.hashes.size());
+        std::vector<uint64_t> rq((size_t)nr * stride, 0), qq((size_t)nq * stride, 0);
+        std::vector<uint32_t> rl(nr), ql(nq);
+        for (uint32_t i = 0; i < nr; ++i) { rl[i] = (uint32_t)R.refs[i].hashes.size(); if (rl[i]) memcpy(&rq[(size_t)i * stride], R.refs[i].hashes.data(), (size_t)rl[i] * 8); }
+        for (uint32_t i = 0; i < nq; ++i) { ql[i] = (uint32_t)Q.refs[i].hashes.size(); if (ql[i]) memcpy(&qq[(size_t)i * stride], Q.refs[i].hashes.data(), (size_t)ql[i] * 8); }
+        std::vector<uint32_t> common((size_t)nq * nr), denom((size_t)nq * nr);
+        std::vector<double> dist((size_t)nq * nr);
+        rc = mhx_dist_batch(qq.data(), ql.data(), nq, rq.data(), rl.data(), nr, stride, k, s, common.data(), denom.data(), dist.data(), 0);
+        if (rc) return rc;
+        for (uint32_t qi = 0; qi < nq; ++qi)
+            for (uint32_t ri = 0; ri < nr; ++ri) {
+                const size_t p = (size_t)qi * nr + ri;
+                const double pv = mhx_p_value(common[p], R.refs[ri].length, Q.refs[qi].length, k, denom[p]);
+                text += R.refs[ri].name + "\t" + Q.refs[qi].name + "\t" + fmt_g(dist[p]) + "\t" + fmt_g(pv) + "\t" +
+                        std::to_string(common[p]) + "/" + std::to_string(denom[p]) + "\n";
+            }
+    }
+    return put_text(text, stdout_buf, cap, need);
+}
+
+extern "C" int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_refs, const char *const *names,
+                             const char *const *comments, const uint64_t *lengths, const uint64_t *const *hashes,
+                             const uint32_t *n_hashes)
+{
+    clear_error();
+    if (!path || (n_refs && (!names || !comments || !lengths || !hashes || !n_hashes))) return fail(MHX_E_ARG, "null argument");
+    SketchSet set;
+    set.kmer_size = (uint32_t)k;
+    set.sketch_size = s;
+    set.refs.resize(n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        set.refs[i].name = names[i] ? names[i] : "";
+        set.refs[i].comment = comments[i] ? comments[i] : "";
+        set.refs[i].length = lengths[i];
+        if (n_hashes[i]) set.refs[i].hashes.assign(hashes[i], hashes[i] + n_hashes[i]);
+    }
+    return msh_write_file(path, set);
+}

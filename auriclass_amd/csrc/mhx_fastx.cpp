@@ -1,0 +1,173 @@
+// mhx_fastx.cpp -- host-side ingest: (gz) file -> bytes, and the record reader used when a
+// stream cannot go to the device parser as it is (FASTA line unwrapping, multi-line FASTQ).
+// Mirrors what `mash sketch` does with zlib + kseq.h before its hot loop (Mash 2.x
+// Sketch.cpp sketchFile); the files are the ones AuriClass passes through unchanged at
+// /root/reference/auriclass/classes.py:588 and :705.
+#include <string.h>
+#include <zlib.h>
+
+#include "mhx_internal.h"
+
+namespace mhx {
+
+int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
+{
+    gzFile g = gzopen(path, "rb"); // transparent for uncompressed files, like mash
+    if (!g) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
+    gzbuffer(g, 1 << 20);
+    out.clear();
+    size_t cap = 1 << 22;
+    out.resize(cap);
+    size_t n = 0;
+    for (;;) {
+        if (n == cap) { cap *= 2; out.resize(cap); }
+        const size_t want = cap - n > (1u << 30) ? (1u << 30) : cap - n;
+        const int got = gzread(g, out.data() + n, (unsigned)want);
+        if (got < 0) { gzclose(g); return fail(MHX_E_IO, "ERROR: reading %s failed", path); }
+        if (got == 0) break;
+        n += (size_t)got;
+    }
+    gzclose(g);
+    out.resize(n);
+    return MHX_OK;
+}
+
+static inline bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+void first_header(const uint8_t *buf, size_t n, std::string &name, std::string &comment)
+{
+    name.clear();
+    comment.clear();
+    size_t p = 0;
+    while (p < n && buf[p] != '>' && buf[p] != '@') ++p;
+    if (p >= n) return;
+    size_t e = ++p;
+    while (e < n && buf[e] != '\n') ++e;
+    size_t end = e;
+    if (end > p && buf[end - 1] == '\r') --end;
+    size_t sp = p;
+    while (sp < end && buf[sp] != ' ' && buf[sp] != '\t') ++sp;
+    name.assign(reinterpret_cast<const char *>(buf + p), sp - p);
+    if (sp < end) comment.assign(reinterpret_cast<const char *>(buf + sp + 1), end - sp - 1);
+}
+
+// Cheap host-side plausibility test for the device FASTQ parser: starts with '@', and the
+// first record has the 4-line shape.  The device verifies every record (kFlagBadFastq).
+bool looks_like_fastq4(const uint8_t *buf, size_t n)
+{
+    if (n == 0 || buf[0] != '@') return false;
+    const uint8_t *l1 = (const uint8_t *)memchr(buf, '\n', n);
+    if (!l1) return false;
+    const uint8_t *l2 = (const uint8_t *)memchr(l1 + 1, '\n', n - (l1 + 1 - buf));
+    if (!l2 || l2 + 1 >= buf + n) return false;
+    return l2[1] == '+';
+}
+
+// Record reader with kseq.h semantics: a record starts at '>' or '@'; name = header up to
+// the first blank, comment = rest of the line; sequence = following lines (blanks removed)
+// up to a line starting with '>', '@' or '+'; after '+' the quality is consumed until it is
+// as long as the sequence.  Records shorter than k are dropped before they count.
+int parse_fastx(const uint8_t *buf, size_t n, int k, ParsedRecords &out)
+{
+    size_t p = 0;
+    while (p < n && buf[p] != '>' && buf[p] != '@') ++p;
+    out.seq.reserve(out.seq.size() + (n - p) / 2 + 16);
+    while (p < n) {
+        // header
+        size_t e = p + 1;
+        while (e < n && buf[e] != '\n') ++e;
+        const size_t hdr_begin = p + 1;
+        size_t hdr_end = e;
+        if (hdr_end > hdr_begin && buf[hdr_end - 1] == '\r') --hdr_end;
+        p = e < n ? e + 1 : n;
+        // sequence lines
+        const size_t seq_start = out.seq.size();
+        while (p < n && buf[p] != '>' && buf[p] != '@' && buf[p] != '+') {
+            size_t le = p;
+            while (le < n && buf[le] != '\n') ++le;
+            for (size_t q = p; q < le; ++q) {
+                const uint8_t c = buf[q];
+                if (c > ' ' && c != 127) out.seq.push_back(c);
+            }
+            p = le < n ? le + 1 : n;
+        }
+        const size_t len = out.seq.size() - seq_start;
+        if (p < n && buf[p] == '+') {
+            while (p < n && buf[p] != '\n') ++p;
+            if (p < n) ++p;
+            size_t ql = 0;
+            while (p < n && ql < len) {
+                size_t le = p;
+                while (le < n && buf[le] != '\n') ++le;
+                for (size_t q = p; q < le; ++q) if (buf[q] > ' ' && buf[q] != 127) ++ql;
+                p = le < n ? le + 1 : n;
+            }
+            if (ql != len) return fail(MHX_E_FORMAT, "truncated quality string in FASTQ record %llu", (unsigned long long)out.records_seen + 1);
+            while (p < n && buf[p] != '>' && buf[p] != '@') ++p;
+        }
+        ++out.records_seen;
+        if (len < (size_t)k) {
+            out.skipped_short = true;
+            out.seq.resize(seq_start);
+            continue;
+        }
+        if (out.records == 0) {
+            size_t sp = hdr_begin;
+            while (sp < hdr_end && buf[sp] != ' ' && buf[sp] != '\t') ++sp;
+            out.first_name.assign(reinterpret_cast<const char *>(buf + hdr_begin), sp - hdr_begin);
+            out.first_comment.clear();
+            if (sp < hdr_end) out.first_comment.assign(reinterpret_cast<const char *>(buf + sp + 1), hdr_end - sp - 1);
+        }
+        ++out.records;
+        out.total_length += len;
+        out.seq.push_back('\n'); // record separator: no k-mer spans two records
+    }
+    return MHX_OK;
+}
+
+} // namespace mhx
+
+// ---- C ABI: sniffers and FASTA size (replace the pyfastx calls of the reference) ----------
+using namespace mhx;
+
+// pyfastx.Fastq / pyfastx.Fasta accept a file when its first record parses in that format
+// (/root/reference/auriclass/general.py:68-115).  Same decision from the first bytes.
+static int sniff(const char *path, char lead)
+{
+    gzFile g = gzopen(path, "rb");
+    if (!g) return fail(MHX_E_IO, "cannot open %s", path);
+    uint8_t buf[1 << 16];
+    const int got = gzread(g, buf, sizeof(buf));
+    gzclose(g);
+    if (got < 0) return 0; // unreadable as text: neither format
+    int p = 0;
+    while (p < got && is_space(buf[p])) ++p;
+    if (p >= got || buf[p] != (uint8_t)lead) return 0;
+    // one header line followed by at least one sequence character
+    const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', got - p);
+    if (!nl || nl + 1 >= buf + got) return 0;
+    const uint8_t c = nl[1];
+    if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '*' || c == '-')) return 0;
+    if (lead == '@') {
+        const uint8_t *nl2 = (const uint8_t *)memchr(nl + 1, '\n', got - (nl + 1 - buf));
+        if (!nl2 || nl2 + 1 >= buf + got || nl2[1] != '+') return 0;
+    }
+    return 1;
+}
+
+extern "C" int mhx_sniff_fastq(const char *path) { clear_error(); return path ? sniff(path, '@') : fail(MHX_E_ARG, "null path"); }
+extern "C" int mhx_sniff_fasta(const char *path) { clear_error(); return path ? sniff(path, '>') : fail(MHX_E_ARG, "null path"); }
+
+extern "C" int mhx_fasta_total_bases(const char *path, uint64_t *total)
+{
+    clear_error();
+    if (!path || !total) return fail(MHX_E_ARG, "null argument");
+    std::vector<uint8_t> raw;
+    int rc = read_all_maybe_gz(path, raw);
+    if (rc) return rc;
+    ParsedRecords pr;
+    rc = parse_fastx(raw.data(), raw.size(), 0, pr);
+    if (rc) return rc;
+    *total = pr.total_length;
+    return MHX_OK;
+}

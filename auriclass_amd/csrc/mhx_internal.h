@@ -1,0 +1,55 @@
+// mhx_internal.h -- host-side internals of libmhx (not part of the C ABI).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mhx.h"
+
+namespace mhx {
+
+// ---- errors ---------------------------------------------------------------------------
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+// ---- sketch container (mhx_msh.cpp) -----------------------------------------------------
+struct RefSketch {
+    std::string name, comment;
+    uint64_t length = 0;
+    std::vector<uint64_t> hashes; // ascending; values < 2^32 when the sketch uses 32-bit hashes
+    std::vector<uint32_t> counts; // optional (empty unless present in the file)
+};
+struct SketchSet {
+    uint32_t kmer_size = 0, sketch_size = 0, window_size = 0, hash_seed = 42;
+    bool concatenated = true, noncanonical = false, preserve_case = false;
+    float error = 0.f;
+    std::string alphabet = "ACGT";
+    std::vector<RefSketch> refs;
+    bool use64() const { return kmer_size > 16; } // 4^k > 2^32
+};
+int msh_serialize(const SketchSet &s, std::vector<uint8_t> &out);
+int msh_write_file(const char *path, const SketchSet &s);
+int msh_read_file(const char *path, SketchSet &s);
+
+// ---- FASTA/FASTQ ingest (mhx_fastx.cpp) -------------------------------------------------
+int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);
+struct ParsedRecords {
+    std::vector<uint8_t> seq;  // bases of counted records, '\n' after each record (MHX_FMT_SEQ)
+    uint64_t records = 0;      // records with length >= k (mash's `count`)
+    uint64_t records_seen = 0; // all records
+    uint64_t total_length = 0; // sum of counted record lengths
+    bool skipped_short = false;
+    std::string first_name, first_comment;
+};
+// kseq-compatible record reader over an inflated buffer (FASTA, FASTQ, multi-line either)
+int parse_fastx(const uint8_t *buf, size_t n, int k, ParsedRecords &out);
+bool looks_like_fastq4(const uint8_t *buf, size_t n);
+void first_header(const uint8_t *buf, size_t n, std::string &name, std::string &comment);
+
+// ---- statistics / text (mhx_text.cpp) ---------------------------------------------------
+double binomial_cdf(uint64_t x, double p, uint64_t n);        // P[X <= x]
+double binomial_sf_ge(uint64_t x, double p, uint64_t n);      // P[X >= x]
+std::string fmt_g(double v);
+std::string bounds_text(int k, double prob);
+
+} // namespace mhx

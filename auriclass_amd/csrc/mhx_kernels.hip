@@ -1,0 +1,399 @@
+// mhx_kernels.hip -- gfx950 kernels of the sketch + distance engine.
+//
+//   sketch_tile_kernel<K,FMT>  one workgroup per 32 KiB tile of the FASTQ / sequence byte
+//                              stream: stage -> classify -> (FASTQ) decoupled look-back for
+//                              the line phase -> valid k-mer starts -> LDS work list ->
+//                              canonical k-mer + MurmurHash3_x64_128 -> admission -> table
+//   table_hist / table_select  tighten the admission threshold T from the candidate table
+//   table_extract              compact (hash,count) entries <= limit for the host / all-gather
+//   dist_pairs_kernel          mash compareSketches for a batch of (query, ref) pairs
+//
+// Replaces the loops inside the `mash sketch` / `mash dist` child processes that
+// /root/reference/auriclass/classes.py:576-596, 696-713 and 92-104 spawn.
+#include "mhx_device.h"
+#include "mhx_tile.h"
+
+namespace mhx {
+
+// ---------------------------------------------------------------------------------------
+// candidate table: open addressing, keys claimed with a 64-bit CAS, counts by atomic add.
+// Only atomics touch the table inside a launch, so no cross-XCD visibility protocol is
+// needed; the next kernel on the stream reads it with plain loads.
+// ---------------------------------------------------------------------------------------
+struct DeviceInserter {
+    unsigned long long *keys;
+    uint32_t *cnts;
+    uint64_t mask;
+    unsigned long long *stats; // this block's replica
+    __device__ __forceinline__ void operator()(uint64_t h)
+    {
+        if (h == kEmptyKey) {
+            atomicAdd(&stats[kStatMaxKey], 1ull);
+            return;
+        }
+        uint64_t slot = h & mask;
+        for (int probe = 0; probe < 8192; ++probe) {
+            const unsigned long long prev = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)h);
+            if (prev == kEmptyKey || prev == h) {
+                atomicAdd(&cnts[slot], 1u);
+                return;
+            }
+            slot = (slot + 1) & mask;
+        }
+        atomicOr(&stats[kStatFlags], (unsigned long long)kFlagTableFull);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Decoupled look-back over per-tile newline counts (wave 0 of the block).
+// tile_state[t] is ONE naturally aligned 8-byte word {flag:32 | value:32} written by one
+// agent-scope store and polled by agent-scope loads: flag 1 = this tile's own count,
+// flag 2 = inclusive prefix up to and including this tile.  Tiles are handed out by an
+// atomic ticket, so every predecessor of a running tile is itself running or done and
+// publishes its own count without waiting on anyone: the wait below always ends.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_state(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ uint32_t lookback_wave(uint64_t *state, uint32_t tile, uint32_t first_tile, uint32_t agg,
+                                  unsigned long long *stats)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr uint64_t A = 1ull << 32, P = 2ull << 32;
+    if (tile == first_tile) {
+        if (lane == 0) st_state(&state[tile], P | agg);
+        return 0;
+    }
+    if (lane == 0) st_state(&state[tile], A | agg);
+    uint32_t excl = 0;
+    int64_t pos = (int64_t)tile - 1;
+    for (uint32_t spins = 0;;) {
+        const int64_t idx = pos - lane;
+        const uint64_t w = idx >= (int64_t)first_tile ? ld_state(&state[idx]) : P; // before the push: prefix 0
+        const uint32_t f = (uint32_t)(w >> 32);
+        const uint64_t notready = __ballot(f == 0);
+        const uint64_t isp = __ballot(f == 2);
+        uint64_t take = 0; // lanes whose value is added
+        bool done = false;
+        if (isp) {
+            const int j = __builtin_ctzll(isp);
+            const uint64_t below = j ? (~0ull >> (64 - j)) : 0ull;
+            if ((notready & below) == 0) {
+                take = below | (1ull << j);
+                done = true;
+            }
+        } else if (!notready) {
+            take = ~0ull;
+        }
+        if (take) {
+            uint32_t v = ((take >> lane) & 1ull) ? (uint32_t)w : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            excl += v;
+            if (done) break;
+            pos -= 64;
+            continue;
+        }
+        if (++spins > (1u << 24)) { // ~seconds; never reached in a healthy launch
+            if (lane == 0) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagSpinTimeout);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (lane == 0) st_state(&state[tile], P | (uint64_t)(excl + agg));
+    return excl;
+}
+
+// ---------------------------------------------------------------------------------------
+template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_kernel(const HashArgs a)
+{
+    __shared__ TileSmem sm;
+    constexpr bool FASTQ = (FMT == 1);
+    const int tid = threadIdx.x;
+
+    // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
+    uint32_t tile;
+    if (FASTQ) {
+        if (tid == 0) sm.misc[2] = a.tile0 + atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        tile = sm.misc[2];
+    } else {
+        tile = a.tile0 + blockIdx.x;
+    }
+    const uint64_t tile_off = (uint64_t)tile * kTileBytes;
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(a.stats) + (tile % kStatReplicas) * kStatCount;
+    if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; }
+
+    phase_stage(sm, tid, a.base, tile_off, a.end);
+    __syncthreads();
+
+    ThreadState st;
+    phase_classify<FASTQ>(sm, tid, st, tile_off, a.begin, a.end);
+
+    uint32_t line_base = 0, excl = 0, tile_total = 0;
+    if (FASTQ) {
+        __syncthreads();
+        excl = prefix_cnt(sm, tid);
+        if (tid == kBlock - 1) sm.misc[5] = excl + st.nlcount;
+        __syncthreads();
+        tile_total = sm.misc[5];
+        if (tid < 64) {
+            const uint32_t lb = lookback_wave(a.tile_state, tile, a.first_tile, tile_total, stats);
+            if (tid == 0) sm.misc[0] = lb;
+        }
+        __syncthreads();
+        line_base = sm.misc[0];
+    }
+    bool bad = false;
+    // the format look-ahead may only read staged bytes that belong to the span
+    const uint64_t span_left = a.end > tile_off ? a.end - tile_off : 0;
+    const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
+    phase_good<FASTQ>(sm, tid, st, line_base, excl, tile_total, check_limit, bad);
+    if (FASTQ && bad) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagBadFastq);
+    __syncthreads();
+
+    const uint32_t kmers = phase_runs<K>(sm, tid);
+    if (kmers) atomicAdd(&sm.misc[3], kmers);
+    __syncthreads();
+
+    phase_compact(sm, tid, prefix_cnt(sm, tid));
+    __syncthreads();
+
+    const uint32_t nitems = sm.misc[1];
+    const uint64_t T = *a.thresh;
+    DeviceInserter ins{reinterpret_cast<unsigned long long *>(a.keys), a.cnts, a.slot_mask, stats};
+    uint32_t ninsert = 0;
+    for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K>(sm, sm.list[it], T, a.hash32 != 0, ins);
+    if (ninsert) atomicAdd(&sm.misc[4], ninsert);
+    __syncthreads();
+    if (tid == 0) {
+        if (sm.misc[3]) atomicAdd(&stats[kStatKmers], (unsigned long long)sm.misc[3]);
+        if (sm.misc[4]) atomicAdd(&stats[kStatInserts], (unsigned long long)sm.misc[4]);
+        if (FASTQ && tile_total) atomicAdd(&stats[kStatLines], (unsigned long long)tile_total);
+    }
+}
+
+template <int K> static hipError_t launch_k(int fmt, const HashArgs &a, hipStream_t st)
+{
+    if (fmt == 1) hipLaunchKernelGGL((sketch_tile_kernel<K, 1>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((sketch_tile_kernel<K, 0>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+#define MHX_K_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
+bool hash_k_supported(int k) { return k >= 1 && k <= 32; }
+
+hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st)
+{
+    if (a.ntiles == 0) return hipSuccess;
+    switch (k) {
+#define X(KK) case KK: return launch_k<KK>(fmt, a, st);
+        MHX_K_LIST(X)
+#undef X
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Threshold tightening.  T only ever decreases, and only to a value below which at least
+// s entries with count >= m already exist, so every hash of the final sketch stays admitted
+// (and therefore fully counted) for the whole run.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
+{
+    __shared__ uint32_t h[kHistBins];
+    __shared__ uint32_t occ_s, solid_s;
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) h[i] = 0;
+    if (threadIdx.x == 0) { occ_s = 0; solid_s = 0; }
+    __syncthreads();
+    const uint64_t T = *a.thresh;
+    const int lz = T ? __builtin_clzll(T) : 63;
+    uint32_t occ = 0, solid = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = a.keys[i];
+        if (key == kEmptyKey) continue;
+        ++occ;
+        if (key <= T && a.cnts[i] >= a.min_mult) {
+            ++solid;
+            atomicAdd(&h[(key << lz) >> (64 - 11)], 1u);
+        }
+    }
+    if (occ) atomicAdd(&occ_s, occ);
+    if (solid) atomicAdd(&solid_s, solid);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
+    if (threadIdx.x == 0) {
+        if (occ_s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.acc[0]), (unsigned long long)occ_s);
+        if (solid_s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.acc[1]), (unsigned long long)solid_s);
+    }
+}
+
+__global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
+{
+    // one block: prefix over the histogram, first bin where the cumulative count reaches s
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t cut;
+    const int t = threadIdx.x;
+    const uint32_t c0 = a.hist[2 * t], c1 = a.hist[2 * t + 1];
+    part[t] = c0 + c1;
+    if (t == 0) cut = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int i = 0; i < t; ++i) before += part[i];
+    __syncthreads();
+    const uint32_t s = a.sketch_size;
+    if (before < s && before + c0 >= s) atomicMin(&cut, (uint32_t)(2 * t));
+    else if (before + c0 < s && before + c0 + c1 >= s) atomicMin(&cut, (uint32_t)(2 * t + 1));
+    a.hist[2 * t] = 0;
+    a.hist[2 * t + 1] = 0;
+    __syncthreads();
+    if (t == 0) { // publish this pass's totals (replica 0), clear the accumulators
+        a.stats[kStatOccupied] = a.acc[0];
+        a.stats[kStatSolid] = a.acc[1];
+        a.acc[0] = 0;
+        a.acc[1] = 0;
+    }
+    if (t == 0 && cut != 0xFFFFFFFFu) {
+        const uint64_t T = *a.thresh;
+        const int lz = T ? __builtin_clzll(T) : 63;
+        if (lz <= 52) {
+            const uint64_t edge = (((uint64_t)cut + 1) << (53 - lz)) - 1; // last value of bin `cut`
+            if (edge < T) *a.thresh = edge;
+        }
+    }
+}
+
+hipError_t launch_tighten(const TableArgs &a, hipStream_t st)
+{
+    uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(table_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(table_select_kernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, uint64_t limit, uint32_t min_count,
+                                                            uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
+                                                            uint32_t *out_n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = a.keys[i];
+        if (key == kEmptyKey || key > limit) continue;
+        const uint32_t c = a.cnts[i];
+        if (c < min_count) continue;
+        const uint32_t pos = atomicAdd(out_n, 1u);
+        if (pos < cap) { out_keys[pos] = key; out_cnts[pos] = c; }
+    }
+}
+
+hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
+                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, hipStream_t st)
+{
+    uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
+                       out_cnts, cap, out_n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// mash compareSketches for one (query, ref) pair per workgroup (Mash 2.x
+// CommandDistance.cpp; invoked by /root/reference/auriclass/classes.py:92-104).
+// The two ascending lists are merged along 256 merge-path diagonals.  In merged order
+// (ties: ref copy first) the query copy of a shared hash directly follows the ref copy, so
+//   common = #query copies whose distinct-rank (position - shared copies so far) <= s
+//   denom  = min(s, |ref| + |qry| - shared)
+// which is exactly what the sequential two-pointer loop with its tail completion yields.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t merge_path(const uint64_t *A, uint32_t nA, const uint64_t *B, uint32_t nB, uint32_t diag)
+{ // number of A elements among the first `diag` merged elements (A first on ties)
+    uint32_t lo = diag > nB ? diag - nB : 0, hi = diag < nA ? diag : nA;
+    while (lo < hi) {
+        const uint32_t i = (lo + hi) >> 1, j = diag - 1 - i;
+        if (A[i] <= B[j]) lo = i + 1; else hi = i;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void dist_pairs_kernel(const DistArgs a)
+{
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t total_common;
+    const uint32_t pair = blockIdx.x;
+    const uint32_t qi = pair / a.nr, ri = pair % a.nr;
+    const uint64_t *A = a.r + (uint64_t)ri * a.stride; // ref
+    const uint64_t *B = a.q + (uint64_t)qi * a.stride; // query
+    const uint32_t nA = a.r_len[ri], nB = a.q_len[qi];
+    const uint32_t total = nA + nB;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (total + 255) / 256;
+    const uint32_t d0 = min(t * per, total), d1 = min(d0 + per, total);
+    const uint32_t i0 = merge_path(A, nA, B, nB, d0), i1 = merge_path(A, nA, B, nB, d1);
+    const uint32_t j0 = d0 - i0, j1 = d1 - i1;
+    // pass 1: shared copies in my segment (a query element equal to the ref element before it)
+    uint32_t c = 0;
+    {
+        uint32_t i = i0, j = j0;
+        while (i < i1 || j < j1) {
+            if (i < i1 && (j >= j1 || A[i] <= B[j])) ++i;
+            else { if (i > 0 && A[i - 1] == B[j]) ++c; ++j; }
+        }
+    }
+    part[t] = c;
+    if (t == 0) total_common = 0;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t x = 0; x < 256; ++x) { const uint32_t v = part[x]; all += v; if (x < t) before += v; }
+    // pass 2: count the shared copies whose distinct rank is within s
+    uint32_t counted = 0;
+    if (c) {
+        uint32_t i = i0, j = j0, pos = d0, seen = before;
+        while (i < i1 || j < j1) {
+            ++pos;
+            if (i < i1 && (j >= j1 || A[i] <= B[j])) ++i;
+            else {
+                if (i > 0 && A[i - 1] == B[j]) { ++seen; if (pos - seen <= a.s) ++counted; }
+                ++j;
+            }
+        }
+    }
+    if (counted) atomicAdd(&total_common, counted);
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t uni = total - all;
+        const uint32_t denom = uni < a.s ? uni : a.s;
+        const uint32_t common = total_common;
+        a.common[pair] = common;
+        a.denom[pair] = denom;
+        if (a.dist) {
+            double d;
+            if (common == denom) d = 0.0;
+            else if (common == 0) d = 1.0;
+            else {
+                const double jac = (double)common / (double)denom;
+                d = -log(2.0 * jac / (1.0 + jac)) / (double)a.k;
+                if (d > 1.0) d = 1.0;
+            }
+            a.dist[pair] = d;
+        }
+    }
+}
+
+hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st)
+{
+    const uint64_t pairs = (uint64_t)a.nq * a.nr;
+    if (pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(dist_pairs_kernel, dim3((unsigned)pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace mhx

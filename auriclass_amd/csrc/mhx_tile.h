@@ -1,0 +1,399 @@
+// mhx_tile.h -- per-tile logic of the sketch kernel, written as host+device inline
+// functions: mhx_kernels.hip strings the phases together with __syncthreads(); the CPU
+// phase emulator (tests/emul/tile_emul.cpp) runs the very same functions thread by
+// thread so that indexing and bit logic are checked without a GPU.
+//
+// What one tile does (replaces mash's kseq_read + addMinHashes + getHash hot loop,
+// Mash 2.x Sketch.cpp; reached from /root/reference/auriclass/classes.py:576-596,696-713):
+//   stage     32 KiB (+64 B halo) of the byte stream into LDS, 16 B per lane, coalesced
+//   classify  per byte: newline?  A/C/G/T (either case)?        -> bit masks (SIMD-in-register)
+//   phase     FASTQ: newline prefix -> line number mod 4 == 1 marks sequence lines
+//   runs      valid k-mer starts = runs of >= K good bytes       -> 1 bit per position
+//   compact   groups of 8 start positions with any valid start   -> LDS work list
+//   work      each lane takes a group: 8 windows share one 28..39 byte register chunk;
+//             canonical strand by big-endian compare, MurmurHash3_x64_128(seed 42),
+//             admission test against the global threshold, insert into the device table
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MHX_HD __host__ __device__ __forceinline__
+#else
+#define MHX_HD inline
+struct uint4 { uint32_t x, y, z, w; };
+#endif
+
+#include "mhx_device_consts.h"
+
+namespace mhx {
+
+struct TileSmem {
+    uint4 bytes[(kTileBytes + kHaloBytes) / 16];      // staged stream bytes
+    uint32_t good[(kTileBytes + kHaloBytes) / 32 + 2]; // 1 bit per byte: usable base
+    uint32_t valid[kGroupsPerTile / 4];                // byte g = valid-start mask of group g
+    uint16_t list[kGroupsPerTile];                     // compacted work list (group ids)
+    uint32_t cnt[kBlock];                              // per-thread counts for the prefix sums
+    uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
+};
+
+// per-thread state carried between phases (registers on the GPU)
+struct ThreadState {
+    uint32_t nl[4], acgt[4];       // masks of this thread's four 32-byte words
+    uint32_t hnl[2], hacgt[2];     // thread 0 only: the two halo words
+    uint32_t nlcount;
+};
+
+// ---- byte-parallel helpers ----------------------------------------------------------
+MHX_HD uint32_t zero_byte_flags(uint32_t y)
+{ // 0x80 in every byte of y that is zero (exact, no cross-byte carries)
+    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | y | 0x7F7F7F7Fu);
+}
+MHX_HD uint32_t flags_to_nibble(uint32_t f)
+{ // bits 7,15,23,31 -> bits 0..3
+    return (f * 0x00204081u) >> 28;
+}
+MHX_HD uint32_t perm_lut(uint32_t lut, uint32_t sel)
+{ // out.byte[i] = lut.byte[sel.byte[i]]  (selectors 0..3)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(lut, lut, sel);
+#else
+    uint32_t o = 0;
+    for (int i = 0; i < 4; ++i) o |= ((lut >> (8 * ((sel >> (8 * i)) & 3))) & 0xFFu) << (8 * i);
+    return o;
+#endif
+}
+// order-preserving 2-bit codes of A,C,G,T (either case folded by the caller): 0,1,2,3
+MHX_HD uint32_t base_codes(uint32_t u) { return ((u >> 1) & 0x03030303u) ^ ((u >> 2) & 0x01010101u); }
+constexpr uint32_t kLutFwd = 0x54474341u;  // code -> 'A','C','G','T'
+constexpr uint32_t kLutComp = 0x41434754u; // code -> complement 'T','G','C','A'
+
+MHX_HD uint32_t funnel(uint32_t hi, uint32_t lo, int byte_shift)
+{
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * byte_shift));
+}
+
+// newline and A/C/G/T masks of one 32-byte word (8 dwords at p)
+template <bool WANT_NL> MHX_HD void classify_word(const uint32_t *p, uint32_t &nl, uint32_t &acgt)
+{
+    uint32_t n = 0, a = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const uint32_t v = p[d];
+        if (WANT_NL) n |= flags_to_nibble(zero_byte_flags(v ^ 0x0A0A0A0Au)) << (4 * d);
+        const uint32_t u = v & 0xDFDFDFDFu;
+        const uint32_t asc = perm_lut(kLutFwd, base_codes(u));
+        a |= flags_to_nibble(zero_byte_flags(asc ^ u)) << (4 * d);
+    }
+    nl = n;
+    acgt = a;
+}
+
+// bits of a 32-byte word starting at absolute offset A that lie inside [begin, end)
+MHX_HD uint32_t inrange_mask(uint64_t A, uint64_t begin, uint64_t end)
+{
+    uint32_t m = 0xFFFFFFFFu;
+    if (begin > A) { uint64_t lo = begin - A; m = lo >= 32 ? 0u : (m << lo); }
+    if (end < A + 32) { uint64_t hi = end > A ? end - A : 0; m &= hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u); }
+    return m;
+}
+
+// Bytes of lines whose index is 1 (mod 4), newline bytes excluded.  `line` is the line
+// index at the first byte of the word.  Also verifies the 4-line layout: the line after a
+// newline must start with '@' (index 0 mod 4) or '+' (index 2 mod 4).  tile_bytes/word_off
+// locate the word inside the staged tile for that look-ahead (nullptr: skip the check).
+MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_bytes, uint32_t word_off,
+                             uint32_t check_limit, bool &bad_format)
+{
+    uint32_t m = 0, cur = 0xFFFFFFFFu;
+    while (nl) {
+        const uint32_t b = nl & (0u - nl);
+        const uint32_t below = b - 1u;
+        if ((line & 3u) == 1u) m |= cur & below;
+        cur = ~(below | b);
+        ++line;
+        if (tile_bytes) {
+            const uint32_t pos = word_off + (uint32_t)__builtin_ctz(b) + 1u;
+            if (pos < check_limit) {
+                const uint8_t c = tile_bytes[pos];
+                if (((line & 3u) == 0u && c != '@') || ((line & 3u) == 2u && c != '+')) bad_format = true;
+            }
+        }
+        nl &= nl - 1u;
+    }
+    if ((line & 3u) == 1u) m |= cur;
+    return m;
+}
+
+// bit p of the result is set iff bits p..p+K-1 of the 160-bit window w[0..4] are all set
+// (only the low 128 result bits are returned).  R_{2n} = R_n & (R_n >> n); R_{n+1} = R_n & (w >> n).
+template <int K> MHX_HD void run_starts(const uint32_t (&w)[5], uint32_t (&out)[4])
+{
+    uint32_t cur[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cur[i] = w[i];
+    int len = 1;
+    constexpr int top = K >= 32 ? 5 : K >= 16 ? 4 : K >= 8 ? 3 : K >= 4 ? 2 : K >= 2 ? 1 : 0;
+#pragma unroll
+    for (int b = top - 1; b >= 0; --b) {
+        // double
+        {
+            uint32_t sh[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t hi = (i + 1 < 5) ? cur[i + 1] : 0u;
+                sh[i] = len >= 32 ? hi : (uint32_t)(((((uint64_t)hi) << 32) | cur[i]) >> len);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cur[i] &= sh[i];
+            len *= 2;
+        }
+        if ((K >> b) & 1) {
+            uint32_t sh[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t hi = (i + 1 < 5) ? w[i + 1] : 0u;
+                sh[i] = len >= 32 ? hi : (uint32_t)(((((uint64_t)hi) << 32) | w[i]) >> len);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cur[i] &= sh[i];
+            len += 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = cur[i];
+}
+
+// ---- MurmurHash3_x64_128, seed 42, first 8 output bytes (mash getHash) ----------------
+MHX_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+MHX_HD uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+// w: the K bytes as little-endian dwords, bytes beyond K zero
+template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
+{
+    constexpr uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    constexpr int NBLK = K / 16, TAIL = K & 15;
+    uint64_t h1 = 42, h2 = 42;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
+        uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    if (TAIL > 8) {
+        uint64_t k2 = (uint64_t)w[(4 * NBLK + 2) & 7] | ((uint64_t)w[(4 * NBLK + 3) & 7] << 32);
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (TAIL > 0) {
+        uint64_t k1 = (uint64_t)w[(4 * NBLK) & 7] | ((uint64_t)w[(4 * NBLK + 1) & 7] << 32);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+// ---- phases -------------------------------------------------------------------------
+
+// P1: stage the tile.  chunk c (16 B) of the tile is loaded by thread c % 256.
+MHX_HD void phase_stage(TileSmem &sm, int tid, const uint8_t *base, uint64_t tile_off, uint64_t end)
+{
+    const uint64_t lim = (end + 15) & ~(uint64_t)15; // last readable 16-byte chunk boundary
+    constexpr int kChunks = kTileBytes / 16;          // 2048
+#pragma unroll
+    for (int j = 0; j < kChunks / kBlock; ++j) {
+        const int c = j * kBlock + tid;
+        const uint64_t off = tile_off + (uint64_t)c * 16;
+        uint4 v = {0, 0, 0, 0};
+        if (off < lim) v = *reinterpret_cast<const uint4 *>(base + off);
+        sm.bytes[c] = v;
+    }
+    if (tid < kHaloBytes / 16) {
+        const int c = kChunks + tid;
+        const uint64_t off = tile_off + (uint64_t)c * 16;
+        uint4 v = {0, 0, 0, 0};
+        if (off < lim) v = *reinterpret_cast<const uint4 *>(base + off);
+        sm.bytes[c] = v;
+    }
+}
+
+// P2a: masks of this thread's 128 bytes (and, for thread 0, of the halo)
+template <bool FASTQ>
+MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile_off, uint64_t begin, uint64_t end)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + tid * (kBytesPerThread / 4);
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t nl, ac;
+        classify_word<FASTQ>(p + 8 * w, nl, ac);
+        const uint32_t in = inrange_mask(tile_off + (uint64_t)tid * kBytesPerThread + 32u * w, begin, end);
+        st.nl[w] = nl & in;
+        st.acgt[w] = ac & in;
+        total += (uint32_t)__builtin_popcount(st.nl[w]);
+    }
+    st.nlcount = total;
+    if (tid == 0) {
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(sm.bytes) + kTileBytes / 4;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            uint32_t nl, ac;
+            classify_word<FASTQ>(h + 8 * w, nl, ac);
+            const uint32_t in = inrange_mask(tile_off + kTileBytes + 32u * w, begin, end);
+            st.hnl[w] = nl & in;
+            st.hacgt[w] = ac & in;
+        }
+    }
+    if (FASTQ) sm.cnt[tid] = total;
+}
+
+// exclusive prefix of sm.cnt over threads < tid (dumb broadcast reads; once per tile)
+MHX_HD uint32_t prefix_cnt(const TileSmem &sm, int tid)
+{
+    uint32_t s = 0;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(sm.cnt);
+    int i = 0;
+    for (; i + 4 <= tid; i += 4) { const uint4 v = c4[i / 4]; s += v.x + v.y + v.z + v.w; }
+    for (; i < tid; ++i) s += sm.cnt[i];
+    return s;
+}
+
+// P2c: good-base bits -> sm.good
+template <bool FASTQ>
+MHX_HD void phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t line_base, uint32_t excl,
+                       uint32_t tile_total, uint32_t check_limit, bool &bad_format)
+{
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(sm.bytes);
+    uint32_t line = line_base + excl;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t g = st.acgt[w];
+        if (FASTQ) {
+            g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format);
+            line += (uint32_t)__builtin_popcount(st.nl[w]);
+        }
+        sm.good[tid * 4 + w] = g;
+    }
+    if (tid == 0) {
+        uint32_t hl = line_base + tile_total;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            uint32_t g = st.hacgt[w];
+            if (FASTQ) {
+                bool ignore = false;
+                g &= seqline_mask(st.hnl[w], hl, nullptr, 0, 0, ignore);
+                hl += (uint32_t)__builtin_popcount(st.hnl[w]);
+            }
+            sm.good[kTileBytes / 32 + w] = g;
+        }
+        sm.good[kTileBytes / 32 + 2] = 0;
+        sm.good[kTileBytes / 32 + 3] = 0;
+    }
+}
+
+// P3: valid k-mer starts of this thread's 128 positions -> sm.valid, #items -> sm.cnt
+template <int K> MHX_HD uint32_t phase_runs(TileSmem &sm, int tid)
+{
+    uint32_t w[5], v[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) w[i] = sm.good[tid * 4 + i];
+    run_starts<K>(w, v);
+    uint32_t items = 0, kmers = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sm.valid[tid * 4 + i] = v[i];
+        kmers += (uint32_t)__builtin_popcount(v[i]);
+        items += 4u - (uint32_t)__builtin_popcount(zero_byte_flags(v[i]));
+    }
+    sm.cnt[tid] = items;
+    return kmers;
+}
+
+// P4: append this thread's non-empty groups to the work list
+MHX_HD void phase_compact(TileSmem &sm, int tid, uint32_t excl)
+{
+    uint32_t pos = excl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t v = sm.valid[tid * 4 + i];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if ((v >> (8 * b)) & 0xFFu) sm.list[pos++] = (uint16_t)(tid * 16 + i * 4 + b);
+    }
+    if (tid == kBlock - 1) sm.misc[1] = pos;
+}
+
+// P5: one work item = 8 consecutive window starts sharing one register chunk.
+// ins(h) is called for every valid window whose hash is <= T.
+template <int K, class Ins>
+MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool hash32, Ins &ins)
+{
+    constexpr int NB = kGroup + K - 1; // bytes touched
+    constexpr int ND = (NB + 3) / 4;   // dwords loaded
+    constexpr int NW = (K + 3) / 4;    // dwords of one k-mer
+    const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
+    uint32_t U[ND + 1], R[ND + 1], C[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        U[d] = src[d] & 0xDFDFDFDFu; // fold case: mash upper-cases before hashing
+        C[d] = base_codes(U[d]);
+    }
+    U[ND] = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) R[d] = perm_lut(kLutComp, __builtin_bswap32(C[ND - 1 - d]));
+    R[ND] = 0;
+    uint32_t ninserted = 0;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        const int of = j;               // forward window starts at U byte `of`
+        const int orr = ND * 4 - K - j; // its reverse complement starts at R byte `orr`
+        uint32_t wf[8], wr[8], w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < NW) {
+                wf[i] = funnel(U[of / 4 + i + 1], U[of / 4 + i], of % 4);
+                wr[i] = funnel(R[orr / 4 + i + 1], R[orr / 4 + i], orr % 4);
+            } else {
+                wf[i] = 0;
+                wr[i] = 0;
+            }
+        }
+        if (K % 4) {
+            wf[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+            wr[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+        }
+        // memcmp(fwd, rc, K) <= 0 ? fwd : rc   (big-endian dword compare, first difference decides)
+        bool rc_less = false, decided = false;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t a = __builtin_bswap32(wf[i]), b = __builtin_bswap32(wr[i]);
+            rc_less = decided ? rc_less : (b < a);
+            decided = decided || (a != b);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = rc_less ? wr[i] : wf[i];
+        uint64_t h = murmur3_h1<K>(w);
+        if (hash32) h &= 0xFFFFFFFFull;
+        if (((vm >> j) & 1u) && h <= T) {
+            ins(h);
+            ++ninserted;
+        }
+    }
+    return ninserted;
+}
+
+} // namespace mhx

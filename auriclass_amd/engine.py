@@ -1,0 +1,324 @@
+"""ctypes binding of libmhx.so (include/mhx.h): the GPU engine that stands where AuriClass
+shells out to `mash` (/root/reference/auriclass/classes.py:92-104, 305-318, 576-596, 696-713).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, the calls
+raise :class:`EngineError` instead of computing anything another way.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libmhx.so"
+HEADER_PATH = _PKG.parent / "include" / "mhx.h"
+
+MHX_OK = 0
+MHX_E_NO_DEVICE = -1
+MHX_E_ARG = -2
+MHX_E_IO = -3
+MHX_E_NO_RECORDS = -4
+MHX_E_FORMAT = -5
+MHX_E_HIP = -6
+MHX_E_CAPACITY = -7
+MHX_E_MISMATCH = -8
+MHX_E_INTERNAL = -9
+
+FMT_SEQ = 0
+FMT_FASTQ4 = 1
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mhx error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class NoRecordsError(EngineError):
+    """mash: 'ERROR: Did not find fasta records in ...'"""
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", str(_PKG / "csrc"), "clean"], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", str(_PKG / "csrc")], check=True)
+    return LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def declared_symbols() -> List[str]:
+    """Entry points declared in include/mhx.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mhx_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EngineError(MHX_E_NO_DEVICE, f"{LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                           "there is no CPU fallback")
+    L = ctypes.CDLL(str(LIB_PATH))
+    c = ctypes
+    u64p, u32p = c.POINTER(c.c_uint64), c.POINTER(c.c_uint32)
+    L.mhx_init.argtypes = [c.c_int]
+    L.mhx_last_error.restype = c.c_char_p
+    L.mhx_version.restype = c.c_char_p
+    L.mhx_device_name.argtypes = [c.c_char_p, c.c_size_t]
+    L.mhx_sketch_files.argtypes = [c.POINTER(c.c_char_p), c.c_int, c.c_int, c.c_uint32, c.c_int, c.c_uint32, c.c_char_p,
+                                   c.c_char_p, c.c_size_t, c.POINTER(c.c_size_t), c.POINTER(c.c_double)]
+    L.mhx_dist_files.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_size_t, c.POINTER(c.c_size_t)]
+    L.mhx_bounds.argtypes = [c.c_int, c.c_double, c.c_char_p, c.c_size_t, c.POINTER(c.c_size_t)]
+    L.mhx_fasta_total_bases.argtypes = [c.c_char_p, u64p]
+    L.mhx_sniff_fastq.argtypes = [c.c_char_p]
+    L.mhx_sniff_fasta.argtypes = [c.c_char_p]
+    L.mhx_sketcher_create.argtypes = [c.c_int, c.c_uint32, c.c_uint32, c.c_uint64, c.POINTER(c.c_void_p)]
+    L.mhx_sketcher_destroy.argtypes = [c.c_void_p]
+    L.mhx_sketcher_destroy.restype = None
+    L.mhx_sketcher_reset.argtypes = [c.c_void_p]
+    L.mhx_sketcher_push_device.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_int]
+    L.mhx_sketcher_push_host.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_int]
+    L.mhx_sketcher_sync.argtypes = [c.c_void_p]
+    L.mhx_sketcher_finish.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, u32p]
+    L.mhx_sketcher_stats.argtypes = [c.c_void_p, c.c_void_p]
+    L.mhx_set_profiling.argtypes = [c.c_int]
+    L.mhx_stream.restype = c.c_void_p
+    L.mhx_sketcher_threshold.argtypes = [c.c_void_p, u64p]
+    L.mhx_sketcher_export.argtypes = [c.c_void_p, c.c_uint64, c.c_void_p, c.c_void_p, c.c_uint32, u32p]
+    L.mhx_merge_partials.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint32, c.c_uint32, c.c_void_p, c.c_void_p, u32p]
+    L.mhx_dist_batch.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32,
+                                 c.c_int, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
+    L.mhx_last_dist_kernel_ms.restype = c.c_double
+    L.mhx_p_value.argtypes = [c.c_uint64, c.c_uint64, c.c_uint64, c.c_int, c.c_uint64]
+    L.mhx_p_value.restype = c.c_double
+    L.mhx_msh_write.argtypes = [c.c_char_p, c.c_int, c.c_uint32, c.c_uint32, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
+                                u64p, c.POINTER(u64p), u32p]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc == MHX_OK:
+        return
+    msg = load().mhx_last_error().decode("utf-8", "replace")
+    if rc == MHX_E_NO_RECORDS:
+        raise NoRecordsError(rc, msg)
+    raise EngineError(rc, msg)
+
+
+_initialised = False
+
+
+def init(device: Optional[int] = None) -> None:
+    """Select the GPU (default: LOCAL_RANK or 0). Raises EngineError when none is usable."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if not _initialised else -1
+    _check(load().mhx_init(device))
+    _initialised = True
+
+
+def device_name() -> str:
+    init()
+    buf = ctypes.create_string_buffer(256)
+    _check(load().mhx_device_name(buf, len(buf)))
+    return buf.value.decode()
+
+
+def stream_handle() -> int:
+    init()
+    return load().mhx_stream() or 0
+
+
+def _text_call(fn, *args) -> str:
+    need = ctypes.c_size_t(0)
+    _check(fn(*args, None, 0, ctypes.byref(need)))
+    buf = ctypes.create_string_buffer(need.value)
+    _check(fn(*args, buf, need.value, ctypes.byref(need)))
+    return buf.value.decode("utf-8")
+
+
+# --------------------------------------------------------------------------- file level
+def sketch_files(paths: Sequence, k: int, s: int, out_msh, reads: bool = False, min_mult: int = 1) -> Tuple[str, float]:
+    """`mash sketch [-r -m M] -o OUT -k K -s S paths...` -> (stderr text, estimated genome size)."""
+    init()
+    L = load()
+    arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(str(p)) for p in paths])
+    need = ctypes.c_size_t(0)
+    est = ctypes.c_double(0.0)
+    cap = 4096 + sum(len(str(p)) for p in paths) * 2 + len(str(out_msh))
+    buf = ctypes.create_string_buffer(cap)
+    rc = L.mhx_sketch_files(arr, len(paths), k, s, int(reads), min_mult, os.fsencode(str(out_msh)), buf, cap,
+                            ctypes.byref(need), ctypes.byref(est))
+    if rc == MHX_E_NO_RECORDS:
+        raise NoRecordsError(rc, L.mhx_last_error().decode())
+    _check(rc)
+    return buf.value.decode("utf-8"), est.value
+
+
+def dist_files(ref_msh, qry_msh) -> str:
+    """`mash dist REF QUERY` stdout."""
+    init()
+    return _text_call(load().mhx_dist_files, os.fsencode(str(ref_msh)), os.fsencode(str(qry_msh)))
+
+
+def bounds(k: int, p: float) -> str:
+    """`mash bounds -k K -p P` stdout (host arithmetic; needs no GPU)."""
+    return _text_call(load().mhx_bounds, k, p)
+
+
+def fasta_total_bases(path) -> int:
+    v = ctypes.c_uint64(0)
+    _check(load().mhx_fasta_total_bases(os.fsencode(str(path)), ctypes.byref(v)))
+    return v.value
+
+
+def sniff_fastq(path) -> bool:
+    rc = load().mhx_sniff_fastq(os.fsencode(str(path)))
+    if rc < 0:
+        _check(rc)
+    return bool(rc)
+
+
+def sniff_fasta(path) -> bool:
+    rc = load().mhx_sniff_fasta(os.fsencode(str(path)))
+    if rc < 0:
+        _check(rc)
+    return bool(rc)
+
+
+def p_value(common: int, len_ref: int, len_qry: int, k: int, denom: int) -> float:
+    return load().mhx_p_value(common, len_ref, len_qry, k, denom)
+
+
+def msh_write(path, k: int, s: int, names: Sequence[str], comments: Sequence[str], lengths: Sequence[int],
+              hashes: Sequence[np.ndarray]) -> None:
+    n = len(names)
+    c = ctypes
+    arrs = [np.ascontiguousarray(h, dtype=np.uint64) for h in hashes]
+    u64p = c.POINTER(c.c_uint64)
+    _check(load().mhx_msh_write(
+        os.fsencode(str(path)), k, s, n,
+        (c.c_char_p * n)(*[x.encode() for x in names]), (c.c_char_p * n)(*[x.encode() for x in comments]),
+        (c.c_uint64 * n)(*lengths), (u64p * n)(*[a.ctypes.data_as(u64p) for a in arrs]),
+        (c.c_uint32 * n)(*[len(a) for a in arrs])))
+
+
+# --------------------------------------------------------------------------- buffer level
+class Sketcher:
+    """Device sketch accumulator (one reference)."""
+
+    def __init__(self, k: int, s: int, min_mult: int = 1, expected_bytes: int = 0):
+        init()
+        self.k, self.s, self.m = k, s, max(1, min_mult)
+        h = ctypes.c_void_p()
+        _check(load().mhx_sketcher_create(k, s, self.m, expected_bytes, ctypes.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            load().mhx_sketcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self) -> None:
+        _check(load().mhx_sketcher_reset(self._h))
+
+    def push_device(self, ptr: int, nbytes: int, fmt: int) -> None:
+        _check(load().mhx_sketcher_push_device(self._h, ctypes.c_void_p(ptr), nbytes, fmt))
+
+    def push_host(self, data, fmt: int) -> None:
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        a = np.ascontiguousarray(a)
+        _check(load().mhx_sketcher_push_host(self._h, a.ctypes.data, a.size, fmt))
+
+    def sync(self) -> None:
+        _check(load().mhx_sketcher_sync(self._h))
+
+    def finish(self) -> Tuple[np.ndarray, np.ndarray]:
+        hashes = np.zeros(self.s, dtype=np.uint64)
+        counts = np.zeros(self.s, dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        _check(load().mhx_sketcher_finish(self._h, hashes.ctypes.data, counts.ctypes.data, ctypes.byref(n)))
+        return hashes[:n.value].copy(), counts[:n.value].copy()
+
+    def stats(self) -> dict:
+        raw = np.zeros(8, dtype=np.uint64)
+        _check(load().mhx_sketcher_stats(self._h, raw.ctypes.data))
+        return {"kmers": int(raw[0]), "inserts": int(raw[1]), "lines": int(raw[2]), "flags": int(raw[3]),
+                "occupied": int(raw[4]), "hash_ms": float(raw[5:6].view(np.float64)[0]), "launches": int(raw[6]),
+                "threshold": int(raw[7])}
+
+    def threshold(self) -> int:
+        v = ctypes.c_uint64(0)
+        _check(load().mhx_sketcher_threshold(self._h, ctypes.byref(v)))
+        return v.value
+
+    def export(self, limit: int) -> Tuple[np.ndarray, np.ndarray]:
+        cap = 1 << 16
+        while True:
+            hashes = np.zeros(cap, dtype=np.uint64)
+            counts = np.zeros(cap, dtype=np.uint32)
+            n = ctypes.c_uint32(0)
+            rc = load().mhx_sketcher_export(self._h, limit, hashes.ctypes.data, counts.ctypes.data, cap, ctypes.byref(n))
+            if rc == MHX_E_CAPACITY and n.value > cap:
+                cap = n.value + 16
+                continue
+            _check(rc)
+            return hashes[:n.value].copy(), counts[:n.value].copy()
+
+
+def set_profiling(on: bool) -> None:
+    load().mhx_set_profiling(int(on))
+
+
+def merge_partials(hashes: np.ndarray, counts: np.ndarray, s: int, min_mult: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    oh = np.zeros(s, dtype=np.uint64)
+    oc = np.zeros(s, dtype=np.uint32)
+    n = ctypes.c_uint32(0)
+    _check(load().mhx_merge_partials(hashes.ctypes.data, counts.ctypes.data, hashes.size, s, min_mult,
+                                     oh.ctypes.data, oc.ctypes.data, ctypes.byref(n)))
+    return oh[:n.value].copy(), oc[:n.value].copy()
+
+
+def dist_batch(q: np.ndarray, q_len: np.ndarray, r: np.ndarray, r_len: np.ndarray, k: int, s: int
+               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Host arrays in, host arrays out: common, denom, dist of shape [nq, nr]."""
+    init()
+    q = np.ascontiguousarray(q, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    assert q.ndim == 2 and r.ndim == 2 and q.shape[1] == r.shape[1]
+    q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+    r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+    nq, nr, stride = q.shape[0], r.shape[0], q.shape[1]
+    common = np.zeros((nq, nr), dtype=np.uint32)
+    denom = np.zeros((nq, nr), dtype=np.uint32)
+    dist = np.zeros((nq, nr), dtype=np.float64)
+    _check(load().mhx_dist_batch(q.ctypes.data, q_len.ctypes.data, nq, r.ctypes.data, r_len.ctypes.data, nr, stride,
+                                 k, s, common.ctypes.data, denom.ctypes.data, dist.ctypes.data, 0))
+    return common, denom, dist
+
+
+def dist_batch_device(q_ptr: int, q_len_ptr: int, nq: int, r_ptr: int, r_len_ptr: int, nr: int, stride: int, k: int, s: int,
+                      common_ptr: int, denom_ptr: int, dist_ptr: int) -> float:
+    """Device pointers in and out; returns the kernel time in ms (HIP events on the engine stream)."""
+    init()
+    v = ctypes.c_void_p
+    _check(load().mhx_dist_batch(v(q_ptr), v(q_len_ptr), nq, v(r_ptr), v(r_len_ptr), nr, stride, k, s,
+                                 v(common_ptr), v(denom_ptr), v(dist_ptr), 1))
+    return load().mhx_last_dist_kernel_ms()

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gbases/s sketched (k=21, s=1000) on synthetic FASTQ resident in HBM.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one whole sketch job over this rank's 10 M x 150 bp reads (BASELINE.json configs[2]):
+reset the device table, run the tile kernels over the FASTQ bytes, pull the final sorted
+sketch to host memory; with N > 1 also the cross-rank exchange + merge (weak scaling: every
+rank owns its own 10 M reads, the answer is the sketch of the union).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from auriclass_amd import engine, multigpu, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--s", type=int, default=1000)
+    ap.add_argument("--m", type=int, default=1)
+    ap.add_argument("--genome", type=int, default=12_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    engine.init(local_rank)
+
+    # ---- synthetic input, resident in HBM before anything is timed -------------------------
+    genome = synth.make_genome(args.genome, seed=42)
+    fq = synth.make_fastq(genome, args.reads, args.read_len, seed=43 + rank, device=str(dev),
+                          first_index=rank * args.reads)
+    torch.cuda.synchronize()
+    nbytes = fq.numel()
+    bases = args.reads * args.read_len
+    sk = engine.Sketcher(args.k, args.s, args.m, expected_bytes=nbytes)
+
+    def step():
+        sk.reset()
+        sk.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
+        if world == 1:
+            return sk.finish()
+        t = sk.threshold()
+        return multigpu.exchange_and_merge(t, sk.export, args.s, args.m, engine.merge_partials, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        sk.sync()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        result = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * bases / (elapsed / args.steps) / 1e9
+
+    # ---- dominant kernel: HIP events on the engine's stream around every tile-kernel launch --
+    roofline = None
+    cpu_baseline = None
+    parity = None
+    if rank == 0:
+        engine.set_profiling(True)
+        ms = []
+        for _ in range(3):
+            sk.reset()
+            sk.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
+            sk.finish()
+            st = sk.stats()
+            ms.append(st["hash_ms"])
+        engine.set_profiling(False)
+        kernel_ms = float(np.median(ms))
+        achieved = nbytes / (kernel_ms / 1e3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get("sketch_tile_kernel_hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": "sketch_tile_kernel", "kernel_ms_per_step": round(kernel_ms, 4),
+                    "launches_per_step": st["launches"], "algorithmic_bytes_per_step": nbytes,
+                    "kmers_per_s": round(st["kmers"] / (kernel_ms / 1e3) / 1e9, 3), "kmers_unit": "G k-mers/s"}
+
+        # ---- CPU baseline + parity on a bounded sample of the same workload -------------------
+        if not args.no_cpu_baseline:
+            from oracle import mash_oracle as mo
+
+            n_s = min(args.cpu_sample_reads, args.reads)
+            rb = synth.record_bytes(args.read_len)
+            sample = fq[: n_s * rb].cpu().numpy()
+            data = sample.tobytes()
+            ref = mo.Sketcher(args.k, args.s, args.m)
+            c0 = time.perf_counter()
+            ref.add_fastx(data)
+            want, _ = ref.finish()
+            cpu_s = time.perf_counter() - c0
+            cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": 1,
+                            "kind": "port",
+                            "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input, "
+                                      f"parse + sketch by the C oracle (oracle/mashcore.c), {cpu_s:.1f} s"}
+            sk2 = engine.Sketcher(args.k, args.s, args.m, expected_bytes=sample.size)
+            sk2.push_device(fq.data_ptr(), n_s * rb, engine.FMT_FASTQ4)
+            got, _ = sk2.finish()
+            sk2.close()
+            parity = bool(np.array_equal(got, want))
+
+    if rank == 0:
+        line = {
+            "metric": "Gbases/s sketched (k=21, s=1000)", "value": round(value, 3), "unit": "Gbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic FASTQ {args.reads} x {args.read_len} bp reads per GPU from a "
+                                   f"{args.genome} bp genome, 0.5% substitutions, {nbytes} bytes resident in HBM",
+                       "k": args.k, "s": args.s, "min_multiplicity": args.m,
+                       "parallelism": "1 process/GPU, record shards, all-gather of partial sketches" if world > 1 else "1 GPU"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "parity_on_sample": parity, "sketch_len": int(len(result[0])),
+        }
+        print(json.dumps(line), flush=True)
+    sk.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

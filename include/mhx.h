@@ -1,0 +1,136 @@
+/*
+ * mhx.h -- C ABI of the MI355X-native MinHash sketch + distance engine ("mhx").
+ *
+ * This library is the in-process replacement for the `mash` child processes that
+ * AuriClass spawns.  Every entry point names the reference interface it replaces
+ * (paths relative to /root/reference):
+ *
+ *   mhx_sketch_files  <- `mash sketch [-r -m M] -o OUT -k K -s S files...`
+ *                        auriclass/classes.py:576-596 (FASTQ) and :696-713 (FASTA)
+ *   mhx_dist_files    <- `mash dist REF.msh QUERY.msh`      auriclass/classes.py:92-104
+ *   mhx_bounds        <- `mash bounds -k K -p P`            auriclass/classes.py:305-318
+ *   mhx_init          <- `mash -h` dependency probe         auriclass/general.py:198-205
+ *
+ * The remaining entry points expose the same hot path at buffer granularity (device
+ * or host pointers) for the throughput benchmark, the multi-GPU shard/merge step and
+ * the batched all-vs-refs distance (BASELINE.json configs 3-5).
+ *
+ * Conventions: plain C types only; the caller owns every buffer; functions return
+ * MHX_OK (0) or a negative MHX_E_* code and leave a message for mhx_last_error().
+ * Text outputs use the two-call pattern: pass cap = 0 to learn the size in *need
+ * (including the terminating NUL), then call again with a buffer of that size.
+ * All compute runs on the GPU selected by mhx_init(); there is no CPU fallback:
+ * without a usable HIP device every compute entry point fails with MHX_E_NO_DEVICE.
+ */
+#ifndef MHX_H
+#define MHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHX_OK 0
+#define MHX_E_NO_DEVICE (-1)   /* no HIP device / mhx_init not called                  */
+#define MHX_E_ARG (-2)         /* bad argument                                          */
+#define MHX_E_IO (-3)          /* file cannot be opened / read / written                */
+#define MHX_E_NO_RECORDS (-4)  /* "ERROR: Did not find fasta records in ..." (mash)     */
+#define MHX_E_FORMAT (-5)      /* malformed FASTA/FASTQ/.msh                            */
+#define MHX_E_HIP (-6)         /* HIP runtime error                                     */
+#define MHX_E_CAPACITY (-7)    /* caller buffer too small / device table exhausted      */
+#define MHX_E_MISMATCH (-8)    /* sketches with different k / seed (mash refuses too)   */
+#define MHX_E_INTERNAL (-9)
+
+/* input stream formats for mhx_sketcher_push_* */
+#define MHX_FMT_SEQ 0     /* dense sequence bytes; any non-ACGT byte (e.g. '\n') ends a k-mer run */
+#define MHX_FMT_FASTQ4 1  /* strict 4-line FASTQ records, parsed on the device                      */
+
+/* ---- library ---------------------------------------------------------------------- */
+int mhx_init(int device);              /* selects the GPU, creates the stream; idempotent */
+void mhx_shutdown(void);
+const char *mhx_last_error(void);      /* thread-local message of the last failure        */
+const char *mhx_version(void);
+int mhx_device_name(char *buf, size_t cap);
+
+/* ---- file level: what classes.py calls today through subprocess ---------------------- */
+
+/* `mash sketch`.  reads != 0 => `-r -m min_mult`: all files form ONE reference whose
+ * length is the set-size estimate; reads == 0 => one reference per file.  Writes the
+ * unpacked Cap'n Proto sketch to out_msh and mash's stderr text (incl. the
+ * "Estimated genome size: %g" line in reads mode) to stderr_buf.
+ * est_genome_size may be NULL. */
+int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads,
+                     uint32_t min_mult, const char *out_msh, char *stderr_buf, size_t stderr_cap,
+                     size_t *stderr_need, double *est_genome_size);
+
+/* `mash dist REF QUERY` stdout: rows "ref\tquery\tdist\tp\tcommon/denom\n", query-major. */
+int mhx_dist_files(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need);
+
+/* `mash bounds -k K -p P` stdout. */
+int mhx_bounds(int k, double p, char *buf, size_t cap, size_t *need);
+
+/* FASTA base count (replaces pyfastx.Fasta(f).size, classes.py:746-751). */
+int mhx_fasta_total_bases(const char *path, uint64_t *total);
+/* format sniffing (replaces pyfastx probes, general.py:68-115): 1 yes, 0 no, <0 error */
+int mhx_sniff_fastq(const char *path);
+int mhx_sniff_fasta(const char *path);
+
+/* ---- buffer level: the hot path itself ------------------------------------------------ */
+typedef struct mhx_sketcher mhx_sketcher;
+
+/* expected_bytes: upper bound of the bytes that will be pushed (sizes the device
+ * candidate table and the initial admission threshold); 0 = unknown/small. */
+int mhx_sketcher_create(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, mhx_sketcher **out);
+void mhx_sketcher_destroy(mhx_sketcher *sk);
+int mhx_sketcher_reset(mhx_sketcher *sk);
+
+/* Feed one record-aligned span.  The device pointer must be readable up to the next
+ * 16-byte boundary past n (true for any hipMalloc/torch allocation).  Asynchronous on
+ * the engine's stream; the buffer must stay valid until finish()/sync(). */
+int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int fmt);
+int mhx_sketcher_push_host(mhx_sketcher *sk, const void *h_bytes, uint64_t n, int fmt);
+int mhx_sketcher_sync(mhx_sketcher *sk);
+
+/* Final sketch: the s smallest distinct hashes with multiplicity >= min_mult, ascending.
+ * hashes/counts must hold s entries (counts may be NULL). */
+int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out);
+
+/* stats of the pushes so far: [0] k-mers hashed, [1] table inserts, [2] lines seen (FASTQ4),
+ * [3] device flags, [4] occupied table slots, [5] hash-kernel ms (profiling on), [6] launches,
+ * [7] threshold */
+int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8);
+int mhx_set_profiling(int on);   /* time hash-kernel launches with HIP events on the engine stream */
+void *mhx_stream(void);          /* the engine's hipStream_t */
+
+/* Multi-GPU: a shard's partial result = every (hash, count) it saw with hash <= limit
+ * (no multiplicity filter).  export_threshold() returns the shard's own admission
+ * threshold; ranks exchange the minimum, export with it, all-gather the slabs and merge. */
+int mhx_sketcher_threshold(mhx_sketcher *sk, uint64_t *threshold);
+int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts,
+                        uint32_t cap, uint32_t *n_out);
+int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s,
+                       uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
+
+/* Batched all-vs-refs `mash dist` arithmetic on the device: q and r are row-major
+ * [n][stride] ascending unique hash lists with q_len/r_len valid entries each.
+ * Outputs are [nq][nr] row-major (query-major like mash): common, denom, distance.
+ * device_ptrs != 0 => q, r, q_len, r_len, common, denom, dist are device pointers. */
+int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r,
+                   const uint32_t *r_len, uint32_t nr, uint32_t stride, int k, uint32_t s,
+                   uint32_t *common, uint32_t *denom, double *dist, int device_ptrs);
+double mhx_last_dist_kernel_ms(void);
+
+/* scalar pieces of the dist row (host): mash pValue() */
+double mhx_p_value(uint64_t common, uint64_t len_ref, uint64_t len_qry, int k, uint64_t denom);
+
+/* .msh container access for callers that hold sketches in memory */
+int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_refs, const char *const *names,
+                  const char *const *comments, const uint64_t *lengths, const uint64_t *const *hashes,
+                  const uint32_t *n_hashes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHX_H */

@@ -27,8 +27,15 @@ def refcwd(tmp_path, monkeypatch):
     """A scratch cwd in which `tests/data/...` resolves to the reference's fixture files,
     so that path strings (which end up inside .msh files and dist rows) are the very
     strings the reference's tests use (tests/test_correct_workflow.py:49-57)."""
-    (tmp_path / "tests").mkdir()
-    os.symlink(REFDATA, tmp_path / "tests" / "data")
+    import gzip
+
+    d = tmp_path / "tests" / "data"
+    d.mkdir(parents=True)
+    for f in REFDATA.iterdir():
+        os.symlink(f, d / f.name)
+    # the reference sketch was made from the uncompressed FASTA files (names end in .fasta)
+    for stem in ("NC_001416.1.fasta", "NC_001604.1.fasta"):
+        (d / stem).write_bytes(gzip.decompress((REFDATA / (stem + ".gz")).read_bytes()))
     (tmp_path / "tmp_data").mkdir()
     monkeypatch.chdir(tmp_path)
     return tmp_path

@@ -1,0 +1,249 @@
+"""GPU parity tests: every call goes through the C ABI of libmhx.so (auriclass_amd.engine)
+and is compared bit for bit with the CPU oracle and with the reference's golden fixtures."""
+import numpy as np
+import pytest
+
+from auriclass_amd import engine, synth
+from oracle import mash_oracle as mo
+from tests.conftest import GOLDEN, REFDATA
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _engine():
+    engine.build()
+    engine.init(0)
+
+
+def oracle_sketch(data: bytes, k, s, m):
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(data)
+    return ref, ref.finish()
+
+
+def random_reads(rng, n, lo, hi, p_n=0.1, p_lower=0.1):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        r = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+        if L and rng.random() < p_n:
+            r[int(rng.integers(0, L))] = ord("N")
+        r = bytes(r)
+        out.append(r.lower() if rng.random() < p_lower else r)
+    return out
+
+
+# ---- buffer level -------------------------------------------------------------------------
+@pytest.mark.parametrize("k,s,m", [(21, 1000, 1), (21, 1000, 3), (27, 50000, 1), (16, 500, 1), (11, 300, 2), (32, 200, 1), (5, 100, 1)])
+def test_seq_stream_equals_oracle(k, s, m):
+    rng = np.random.default_rng(k * 7 + s + m)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=40_000)
+    reads = []
+    for _ in range(3000):
+        st = int(rng.integers(0, len(genome) - 200))
+        reads.append(bytes(genome[st:st + int(rng.integers(5, 200))]))
+    reads += random_reads(rng, 200, 0, 300)
+    data = b"\n".join(reads) + b"\n"
+    sk = engine.Sketcher(k, s, m, expected_bytes=len(data))
+    sk.push_host(data, engine.FMT_SEQ)
+    got_h, got_c = sk.finish()
+    stats = sk.stats()
+    sk.close()
+    want_h, want_c = mo.bruteforce_sketch(reads, k, s, m)
+    assert np.array_equal(got_h, want_h)
+    assert np.array_equal(got_c, want_c)          # device counts are exact multiplicities
+    ref = mo.Sketcher(k, s, m)
+    for r in reads:
+        ref.add_seq(r)
+    assert np.array_equal(got_h, ref.finish()[0])
+    assert stats["kmers"] == ref.kmers
+    assert stats["flags"] == 0
+
+
+@pytest.mark.parametrize("m", [1, 3])
+def test_fastq4_stream_equals_oracle(m):
+    genome = synth.make_genome(300_000, seed=1)
+    fq = synth.make_fastq(genome, 60_000, 150, seed=2, device="cpu").numpy()
+    sk = engine.Sketcher(21, 1000, m, expected_bytes=fq.size)
+    sk.push_host(fq, engine.FMT_FASTQ4)
+    got, cnt = sk.finish()
+    st = sk.stats()
+    sk.close()
+    ref, (want, _) = oracle_sketch(fq.tobytes(), 21, 1000, m)
+    assert len(got) == 1000
+    assert np.array_equal(got, want)
+    assert st["kmers"] == ref.kmers and st["lines"] == 4 * 60_000 and st["flags"] == 0
+    assert st["launches"] >= 2   # the tightening schedule really ran
+
+
+def test_fastq4_ragged_reads_and_unaligned_device_pointer():
+    import torch
+
+    rng = np.random.default_rng(11)
+    reads = random_reads(rng, 4000, 1, 400, p_n=0.3, p_lower=0.3)
+    quals = np.frombuffer(b"!#+@ACGTIJ5<?acgt", np.uint8)
+    rec = [b"@r%d x y\n" % i + r + b"\n+\n" + bytes(rng.choice(quals, size=len(r))) + b"\n" for i, r in enumerate(reads)]
+    data = b"".join(rec)
+    dev = torch.empty(len(data) + 4096, dtype=torch.uint8, device="cuda")
+    for lead in (0, 3, 1000 + 7):
+        dev[lead:lead + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        sk = engine.Sketcher(21, 2000, 1, expected_bytes=len(data))
+        sk.push_device(dev.data_ptr() + lead, len(data), engine.FMT_FASTQ4)
+        got, _ = sk.finish()
+        sk.close()
+        want, _ = mo.bruteforce_sketch(reads, 21, 2000, 1)
+        assert np.array_equal(got, want)
+
+
+def test_multiple_pushes_accumulate_into_one_reference():
+    genome = synth.make_genome(100_000, seed=3)
+    a = synth.make_fastq(genome, 20_000, 150, seed=4, device="cpu").numpy()
+    b = synth.make_fastq(genome, 30_000, 100, seed=5, device="cpu").numpy()
+    sk = engine.Sketcher(21, 1000, 3, expected_bytes=a.size + b.size)
+    sk.push_host(a, engine.FMT_FASTQ4)
+    sk.push_host(b, engine.FMT_FASTQ4)
+    got, _ = sk.finish()
+    sk.reset()
+    sk.push_host(b, engine.FMT_FASTQ4)
+    again, _ = sk.finish()
+    sk.close()
+    _, (want, _) = oracle_sketch(a.tobytes() + b.tobytes(), 21, 1000, 3)
+    assert np.array_equal(got, want)
+    _, (want_b, _) = oracle_sketch(b.tobytes(), 21, 1000, 3)
+    assert np.array_equal(again, want_b)
+
+
+def test_non_fastq4_is_flagged_not_mis_sketched():
+    data = b"@r\nACGTACGTACGTACGTACGTACGTACGT\nACGTACGTACGTACGTACGTACGT\n+\n" + b"I" * 52 + b"\n"
+    sk = engine.Sketcher(21, 100, 1, expected_bytes=len(data))
+    sk.push_host(data * 50, engine.FMT_FASTQ4)
+    with pytest.raises(engine.EngineError) as e:
+        sk.finish()
+    assert e.value.code == engine.MHX_E_FORMAT
+    sk.close()
+
+
+def test_shard_export_and_merge_equals_single_sketch():
+    genome = synth.make_genome(150_000, seed=6)
+    fq = synth.make_fastq(genome, 40_000, 150, seed=7, device="cpu").numpy()
+    rb = synth.record_bytes(150)
+    for m in (1, 3):
+        parts, thr = [], []
+        sks = []
+        for r in range(4):
+            lo, hi = r * 10_000 * rb, (r + 1) * 10_000 * rb
+            sk = engine.Sketcher(21, 1000, m, expected_bytes=hi - lo)
+            sk.push_host(fq[lo:hi], engine.FMT_FASTQ4)
+            thr.append(sk.threshold())
+            sks.append(sk)
+        tmin = min(thr)
+        for sk in sks:
+            parts.append(sk.export(tmin))
+            sk.close()
+        h = np.concatenate([p[0] for p in parts])
+        c = np.concatenate([p[1] for p in parts])
+        got, _ = engine.merge_partials(h, c, 1000, m)
+        _, (want, _) = oracle_sketch(fq.tobytes(), 21, 1000, m)
+        assert np.array_equal(got, want)
+
+
+# ---- file level: the reference's golden vectors ----------------------------
+def test_K1_K2_reference_sketch_bytes(refcwd):
+    out = refcwd / "ref.msh"
+    stderr, _ = engine.sketch_files(["tests/data/NC_001416.1.fasta", "tests/data/NC_001604.1.fasta"], 27, 50000, out)
+    assert out.read_bytes() == (REFDATA / "ref_sketch.msh").read_bytes()
+    assert "Sketching tests/data/NC_001416.1.fasta..." in stderr
+
+
+def test_K3_K4_fastq_workflow_rows(refcwd, golden):
+    out = refcwd / "q.msh"
+    stderr, est = engine.sketch_files(["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz"], 27, 50000, out,
+                                      reads=True, min_mult=3)
+    assert "Estimated genome size: 48454.7\n" in stderr         # test_correct_workflow.py:99
+    assert float("%g" % est) == golden["scalars"]["fastq_estimated_genome_size"]
+    text = engine.dist_files("tests/data/ref_sketch.msh", out)
+    assert text == ("tests/data/NC_001416.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t9.55405e-06\t0\t48451/48476\n"
+                    "tests/data/NC_001604.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t1\t1\t0/50000\n")
+    # same bytes as the oracle's container for the reads-mode sketch
+    osk, _ = mo.sketch_files(["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz"], 27, 50000, reads=True, m=3)
+    assert out.read_bytes() == mo.msh_bytes(osk)
+
+
+def test_K5_fasta_workflow_rows(refcwd):
+    out = refcwd / "q.msh"
+    engine.sketch_files(["tests/data/NC_001416.1.fasta.gz"], 27, 50000, out)
+    text = engine.dist_files("tests/data/ref_sketch.msh", out)
+    assert text == ("tests/data/NC_001416.1.fasta\ttests/data/NC_001416.1.fasta.gz\t0\t0\t48476/48476\n"
+                    "tests/data/NC_001604.1.fasta\ttests/data/NC_001416.1.fasta.gz\t1\t1\t0/50000\n")
+
+
+def test_K8_empty_input_raises_no_records(refcwd):
+    with pytest.raises(engine.NoRecordsError, match="ERROR: Did not find fasta records in"):
+        engine.sketch_files(["tests/data/test_empty_1.fq.gz", "tests/data/test_empty_2.fq.gz"], 27, 50000, refcwd / "e.msh",
+                            reads=True, min_mult=3)
+
+
+def test_multiline_fastq_falls_back_to_record_parser(tmp_path):
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, 300, 60, 200, p_n=0, p_lower=0)
+    rec = []
+    for i, r in enumerate(reads):
+        half = len(r) // 2
+        rec.append(b"@m%d\n" % i + r[:half] + b"\n" + r[half:] + b"\n+\n" + b"I" * half + b"\n" + b"I" * (len(r) - half) + b"\n")
+    p = tmp_path / "multi.fq"
+    p.write_bytes(b"".join(rec))
+    engine.sketch_files([p], 21, 1000, tmp_path / "m.msh", reads=True, min_mult=1)
+    got = mo.read_msh(tmp_path / "m.msh").references[0].hashes
+    want, _ = mo.bruteforce_sketch(reads, 21, 1000, 1)
+    assert np.array_equal(got, want)
+
+
+def test_C2_synthetic_assembly_fasta_k21_s1000(tmp_path):
+    genome = synth.make_genome(1_200_000, seed=42)
+    fa = tmp_path / "asm.fasta"
+    fa.write_bytes(synth.genome_fasta(genome, 20))
+    engine.sketch_files([fa], 21, 1000, tmp_path / "a.msh")
+    osk, _ = mo.sketch_files([fa], 21, 1000)
+    assert (tmp_path / "a.msh").read_bytes() == mo.msh_bytes(osk)
+    # refs: mutated copies, sketched by the oracle, distances by the engine
+    refs = []
+    for i, rate in enumerate([0.0005, 0.005, 0.05]):
+        rp = tmp_path / ("ref%d.fasta" % i)
+        rp.write_bytes(synth.genome_fasta(synth.mutate(genome, rate, 100 + i), 20, name="r%d" % i))
+        refs.append(rp)
+    rsk, _ = mo.sketch_files(refs, 21, 1000)
+    mo.write_msh(tmp_path / "refs.msh", rsk)
+    assert engine.dist_files(tmp_path / "refs.msh", tmp_path / "a.msh") == mo.dist_text(rsk, osk)
+
+
+# ---- batched distance -------------------------------------------------------------------------
+def test_dist_batch_equals_oracle_compare():
+    rng = np.random.default_rng(9)
+    s, k = 3000, 21
+    base = np.unique(rng.integers(0, 2 ** 63, size=4 * s, dtype=np.uint64))
+    refs, qrys = [], []
+    for i in range(5):
+        refs.append(np.sort(rng.choice(base, size=s if i else s - 500, replace=False)))
+    for f in (0.0, 0.01, 0.3, 0.9, 1.0):
+        src = refs[int(rng.integers(0, 5))]
+        keep = src[rng.random(len(src)) >= f]
+        fresh = rng.integers(0, 2 ** 63, size=s - len(keep), dtype=np.uint64)
+        qrys.append(np.unique(np.concatenate([keep, fresh])))
+    qrys.append(refs[0].copy())                        # identical lists
+    qrys.append(np.zeros(0, np.uint64))                # empty query
+    qrys.append(refs[1][:10].copy())                   # short prefix
+    stride = max(max(map(len, refs)), max(map(len, qrys)))
+    R = np.zeros((len(refs), stride), np.uint64)
+    Q = np.zeros((len(qrys), stride), np.uint64)
+    for i, r in enumerate(refs):
+        R[i, :len(r)] = r
+    for i, q in enumerate(qrys):
+        Q[i, :len(q)] = q
+    common, denom, dist = engine.dist_batch(Q, [len(q) for q in qrys], R, [len(r) for r in refs], k, s)
+    for qi, q in enumerate(qrys):
+        for ri, r in enumerate(refs):
+            c, d, dd = mo.compare(r, q, s, k)
+            assert (common[qi, ri], denom[qi, ri]) == (c, d), (qi, ri)
+            assert dist[qi, ri] == dd

@@ -1,0 +1,89 @@
+"""CPU-side checks of libmhx.so: it loads, exports every entry point include/mhx.h declares,
+its host-only pieces (bounds table, .msh container, sniffers) match the reference's goldens,
+and every compute entry point refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from auriclass_amd import engine
+from oracle import mash_oracle as mo
+from tests.conftest import GOLDEN, REFDATA
+
+HAVE_GPU = torch.cuda.is_available()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    engine.build()
+    return engine.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = engine.declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libmhx.so does not export {n}"
+
+
+def test_bounds_text_matches_reference_golden(lib):
+    # /root/reference/tests/test_correct_workflow.py:26
+    assert engine.bounds(27, 0.99) == (GOLDEN / "mash_bounds_k27_p0.99.txt").read_text()
+    assert engine.bounds(21, 0.99) == mo.bounds_text(21, 0.99)
+    assert engine.bounds(16, 0.95) == mo.bounds_text(16, 0.95)
+
+
+def test_msh_writer_reproduces_reference_fixture_bytes(lib, tmp_path):
+    ref = mo.read_msh(REFDATA / "ref_sketch.msh")
+    out = tmp_path / "x.msh"
+    engine.msh_write(out, 27, 50000, [r.name for r in ref.references], [r.comment for r in ref.references],
+                     [r.length for r in ref.references], [r.hashes for r in ref.references])
+    assert out.read_bytes() == (REFDATA / "ref_sketch.msh").read_bytes()
+
+
+@pytest.mark.parametrize("k,nrefs,nh", [(21, 1, 1000), (21, 3, 400), (16, 2, 300), (27, 30, 1000), (21, 1, 0), (31, 200, 7)])
+def test_msh_writer_equals_oracle_writer(lib, tmp_path, k, nrefs, nh):
+    rng = np.random.default_rng(k + nrefs + nh)
+    hi = 2 ** 32 if k <= 16 else 2 ** 64
+    refs = []
+    for i in range(nrefs):
+        h = np.unique(rng.integers(0, hi, size=nh, dtype=np.uint64))
+        refs.append(mo.Reference("name_%d.fa" % i, "c" * int(rng.integers(0, 40)), int(rng.integers(1, 10 ** 7)), h))
+    sk = mo.SketchFile(kmer_size=k, sketch_size=max(nh, 1), references=refs)
+    out = tmp_path / "y.msh"
+    engine.msh_write(out, k, max(nh, 1), [r.name for r in refs], [r.comment for r in refs], [r.length for r in refs],
+                     [r.hashes for r in refs])
+    assert out.read_bytes() == mo.msh_bytes(sk)
+    back = mo.read_msh(out)
+    assert [r.name for r in back.references] == [r.name for r in refs]
+    assert all(np.array_equal(a.hashes, b.hashes) for a, b in zip(back.references, refs))
+
+
+def test_p_value_against_oracle(lib):
+    for x, lr, lq, k, n in [(0, 1000, 1000, 21, 1000), (5, 5_000_000, 4_000_000, 16, 1000), (20, 12_000_000, 12_000_000, 14, 1000),
+                            (48451, 48502, 48454, 27, 48476), (3, 10 ** 9, 10 ** 9, 16, 400)]:
+        got = engine.p_value(x, lr, lq, k, n)
+        want = mo.p_value(x, lr, lq, 4.0 ** k, n)
+        assert got == pytest.approx(want, rel=1e-9, abs=1e-300)
+        assert "%g" % got == "%g" % want
+
+
+def test_sniffers_and_fasta_size(lib):
+    assert engine.sniff_fastq(REFDATA / "NC_001416.1_1.fq.gz") and not engine.sniff_fasta(REFDATA / "NC_001416.1_1.fq.gz")
+    assert engine.sniff_fasta(REFDATA / "NC_001416.1.fasta.gz") and not engine.sniff_fastq(REFDATA / "NC_001416.1.fasta.gz")
+    assert not engine.sniff_fasta(REFDATA / "ref_sketch.msh") and not engine.sniff_fastq(REFDATA / "ref_sketch.msh")
+    assert not engine.sniff_fastq(REFDATA / "test_empty_1.fq.gz")
+    assert engine.fasta_total_bases(REFDATA / "NC_001416.1.fasta.gz") == 48502   # test_correct_workflow.py:197
+    assert engine.fasta_total_bases(REFDATA / "NC_001604.1.fasta.gz") == 39937
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU behaviour")
+def test_compute_calls_fail_loudly_without_gpu(lib, tmp_path):
+    with pytest.raises(engine.EngineError) as e:
+        engine.sketch_files([REFDATA / "NC_001416.1.fasta.gz"], 27, 50000, tmp_path / "o.msh")
+    assert e.value.code == engine.MHX_E_NO_DEVICE
+    with pytest.raises(engine.EngineError):
+        engine.dist_files(REFDATA / "ref_sketch.msh", REFDATA / "ref_sketch.msh")
+    with pytest.raises(engine.EngineError):
+        engine.Sketcher(21, 1000)

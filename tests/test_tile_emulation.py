@@ -1,0 +1,144 @@
+"""CPU emulation of the sketch kernel's tile phases (auriclass_amd/csrc/mhx_tile.h, the very
+functions the HIP kernel runs) against the oracle's definition-level window hashes."""
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import mash_oracle as mo
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "tests" / "emul" / "tile_emul.cpp"
+SO = ROOT / "tests" / "emul" / "_tile_emul.so"
+MAXT = 2 ** 64 - 1
+
+
+@pytest.fixture(scope="module")
+def emul():
+    hdr = ROOT / "auriclass_amd" / "csrc" / "mhx_tile.h"
+    if not SO.exists() or SO.stat().st_mtime < max(SRC.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(SO), str(SRC)], check=True)
+    L = ctypes.CDLL(str(SO))
+    L.emul_sketch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                              ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    return L
+
+
+def run_emul(L, data: bytes, k, fmt, T=MAXT, lead=0):
+    """lead: bytes of foreign data placed before the span (span starts at an unaligned offset)."""
+    pad = 65536
+    raw = np.zeros(lead + len(data) + pad + 64, dtype=np.uint8)
+    base_off = (-raw.ctypes.data) % 16
+    buf = raw[base_off:]
+    rng = np.random.default_rng(7)
+    buf[:lead] = rng.choice(np.frombuffer(b"ACGT\n@+I", np.uint8), size=lead)
+    buf[lead:lead + len(data)] = np.frombuffer(data, np.uint8)
+    buf[lead + len(data):lead + len(data) + 48] = np.frombuffer(b"ACGT" * 12, np.uint8)  # foreign tail
+    out = np.zeros(len(data) + 16, dtype=np.uint64)
+    n = ctypes.c_uint64()
+    stats = np.zeros(8, dtype=np.uint64)
+    rc = L.emul_sketch(buf.ctypes.data, lead, lead + len(data), k, fmt, T, out.ctypes.data, len(out),
+                       ctypes.byref(n), stats.ctypes.data)
+    assert rc == 0
+    return np.sort(out[:n.value]), stats
+
+
+def oracle_hashes(seqs, k):
+    parts = []
+    for s in seqs:
+        if len(s) < k:
+            continue
+        o = np.zeros(len(s), dtype=np.uint64)
+        b = ctypes.create_string_buffer(s, len(s))
+        n = mo.lib().mo_all_window_hashes(b, len(s), k, o.ctypes.data)
+        parts.append(o[:n])
+    return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+
+
+def random_reads(rng, n, lo, hi, p_n=0.2, p_lower=0.2):
+    reads = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        r = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+        if L and rng.random() < p_n:
+            for _ in range(int(rng.integers(1, 3))):
+                r[int(rng.integers(0, L))] = rng.choice(np.frombuffer(b"NRYKM-*", np.uint8))
+        r = bytes(r)
+        if rng.random() < p_lower:
+            r = r.lower()
+        reads.append(r)
+    return reads
+
+
+def fastq_bytes(rng, reads):
+    qual_alphabet = np.frombuffer(b"!#+@ACGTIJ5<?acgt", np.uint8)
+    out = []
+    for i, r in enumerate(reads):
+        q = bytes(rng.choice(qual_alphabet, size=len(r)))
+        out.append(b"@r%d/1 x\n" % i + r + b"\n+\n" + q + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("k", [21, 27, 16, 11, 32, 31, 5, 1])
+def test_seq_stream(emul, k):
+    rng = np.random.default_rng(100 + k)
+    reads = random_reads(rng, 300, 0, 400)
+    data = b"\n".join(reads) + b"\n"
+    got, stats = run_emul(emul, data, k, fmt=0)
+    want = oracle_hashes(reads, k)
+    assert stats[0] == len(want)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k,lead", [(21, 0), (21, 37), (27, 5000), (16, 32768 + 11), (31, 1)])
+def test_fastq4_stream(emul, k, lead):
+    rng = np.random.default_rng(200 + k + lead)
+    reads = random_reads(rng, 700, 1, 260)
+    data = fastq_bytes(rng, reads)
+    assert len(data) > 3 * 32768
+    got, stats = run_emul(emul, data, k, fmt=1, lead=lead)
+    want = oracle_hashes(reads, k)
+    assert int(stats[3]) == 0, "format flag raised on a valid FASTQ"
+    assert int(stats[2]) == 4 * len(reads)
+    assert stats[0] == len(want)
+    assert np.array_equal(got, want)
+
+
+def test_fastq4_no_trailing_newline_and_long_lines(emul):
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, 6, 30000, 70000, p_n=0.5)   # lines longer than a tile
+    data = fastq_bytes(rng, reads)[:-1]
+    got, stats = run_emul(emul, data, 21, fmt=1, lead=3)
+    assert np.array_equal(got, oracle_hashes(reads, 21))
+    assert int(stats[3]) == 0
+
+
+def test_fastq_layout_violation_is_flagged(emul):
+    rng = np.random.default_rng(6)
+    reads = random_reads(rng, 50, 50, 100)
+    good = fastq_bytes(rng, reads)
+    bad = good.replace(b"\n+\n", b"\nX\n", 1)
+    _, stats = run_emul(emul, bad, 21, fmt=1)
+    assert int(stats[3]) & 2
+    multi = b"@r\nACGT\nACGT\n+\nIIIIIIII\n" + good   # multi-line record
+    _, stats = run_emul(emul, multi, 21, fmt=1)
+    assert int(stats[3]) & 2
+
+
+def test_threshold_filter(emul):
+    rng = np.random.default_rng(8)
+    reads = random_reads(rng, 200, 100, 200, p_n=0, p_lower=0)
+    data = b"\n".join(reads)
+    T = 2 ** 60
+    got, stats = run_emul(emul, data, 21, fmt=0, T=T)
+    want = oracle_hashes(reads, 21)
+    assert np.array_equal(got, want[want <= T])
+    assert stats[1] == len(got)
+
+
+def test_empty_and_tiny(emul):
+    for data in (b"", b"A", b"ACGTACGTACGTACGTACGT", b"ACGTACGTACGTACGTACGTA"):
+        got, _ = run_emul(emul, data, 21, fmt=0)
+        assert np.array_equal(got, oracle_hashes([data], 21))
