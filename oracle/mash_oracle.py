@@ -193,7 +193,8 @@ def sketch_files(paths: Sequence, k: int, s: int, reads: bool = False, m: int = 
         if sk.records == 0:
             raise NoRecordsError('ERROR: Did not find fasta records in "%s".' % paths[0])
         hashes, counts = sk.finish()
-        out.references.append(Reference(str(paths[0]), sk.comment(), int(sk.set_size), hashes, counts))
+        # counts32 is only stored with `mash sketch -M`, which AuriClass never passes
+        out.references.append(Reference(str(paths[0]), sk.comment(), int(sk.set_size), hashes, None))
         stderr.append("Estimated genome size: %s" % fmt_g(sk.set_size))
         stderr.append("Estimated coverage:    %s" % fmt_g(sk.multiplicity))
     else:
