@@ -1,0 +1,105 @@
+"""The reference's own integration tests, step for step, against the GPU engine
+(/root/reference/tests/test_correct_workflow.py:41-234, tests/test_failing_workflow.py:51-128,
+and the CI `cmp report.tsv` lines of .github/workflows/test.yaml:58-77)."""
+import tempfile
+
+import pytest
+
+from auriclass_amd.classes import FastaAuriclass, FastqAuriclass
+from auriclass_amd.general import check_dependencies, guess_input_type, validate_input_files
+from auriclass_amd.main import main
+from tests.conftest import GOLDEN, REFDATA
+
+pytestmark = pytest.mark.gpu
+
+COMMON = dict(name="test", output_report_path="tmp_data/test_report.tsv", reference_sketch_path="tests/data/ref_sketch.msh",
+              genome_size_range=(40_000, 60_000), kmer_size=27, sketch_size=50_000, minimal_kmer_coverage=3,
+              clade_config_path="tests/data/clade_config.csv", non_candida_threshold=0.1, high_dist_threshold=0.003, no_qc=False)
+
+
+def as_dict(df):
+    return {c: {str(i): v for i, v in col.items()} for c, col in df.to_dict().items()}
+
+
+def test_fastq(refcwd, golden):
+    reads = ["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz"]
+    validate_input_files(reads)
+    check_dependencies()
+    s = FastqAuriclass(read_paths=reads, **COMMON)
+    with tempfile.TemporaryDirectory() as tmpdir:
+        s.query_sketch_path = f"{tmpdir}/tmpfile.msh"
+        s.sketch_fastq_query()
+        s.run_mash_dist()
+        assert as_dict(s.mash_output) == golden["mash_output_to_dict_fastq"]
+    s.check_genome_size()
+    assert s.estimated_genome_size == 48454.7 and s.qc_genome_size == ""
+    s.select_clade()
+    assert s.clade == "Lambda phage" and s.minimal_distance == 9.55405e-06
+    assert s.closest_sample == "tests/data/NC_001416.1.fasta"
+    assert s.check_non_candida() and s.qc_species == ""
+    assert s.check_for_outgroup() and s.qc_other_candida == ""
+    s.check_high_dist()
+    assert s.qc_high_distance == ""
+    text = s.get_error_bounds()
+    assert text == (GOLDEN / "mash_bounds_k27_p0.99.txt").read_text()
+    s.process_error_bounds(text)
+    assert s.error_bound == 0.0008979
+    s.compare_with_error_bounds()
+    assert s.distances == [1.0] and s.samples_within_error_bound == 0 and s.qc_multiple_hits == ""
+    s.save_report()
+
+
+def test_fasta(refcwd, golden):
+    s = FastaAuriclass(read_paths=["tests/data/NC_001416.1.fasta.gz"], **COMMON)
+    with tempfile.TemporaryDirectory() as tmpdir:
+        s.query_sketch_path = f"{tmpdir}/tmpfile.msh"
+        s.sketch_fasta_query()
+        s.run_mash_dist()
+        assert as_dict(s.mash_output) == golden["mash_output_to_dict_fasta"]
+    s.parse_genome_size()
+    s.check_genome_size()
+    assert s.estimated_genome_size == 48502 and s.qc_genome_size == ""
+    s.select_clade()
+    assert s.clade == "Lambda phage" and s.minimal_distance == 0
+    assert s.check_non_candida() and s.check_for_outgroup()
+    s.check_high_dist()
+    s.process_error_bounds(s.get_error_bounds())
+    assert s.error_bound == 0.0008979
+    s.compare_with_error_bounds()
+    assert s.distances == [1.0] and s.samples_within_error_bound == 0
+    s.save_report()
+
+
+def test_empty_input_files(refcwd):
+    s = FastqAuriclass(read_paths=["tests/data/test_empty_1.fq.gz", "tests/data/test_empty_2.fq.gz"], **COMMON)
+    check_dependencies()
+    with tempfile.TemporaryDirectory() as tmpdir:
+        s.query_sketch_path = f"{tmpdir}/tmpfile.msh"
+        with pytest.raises(ValueError):
+            s.sketch_fastq_query()
+
+
+def test_non_fastq_or_fasta_and_mixed_inputs(refcwd):
+    with pytest.raises(ValueError):
+        guess_input_type(["tests/data/ref_sketch.msh"])
+    with pytest.raises(ValueError):
+        guess_input_type(["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1.fasta.gz"])
+
+
+def test_cli_reports_are_byte_identical_to_the_reference_reports(refcwd):
+    # .github/workflows/test.yaml:58-66
+    main(["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz", "-r", "tests/data/ref_sketch.msh",
+          "-c", "tests/data/clade_config.csv", "--expected_genome_size", "40000", "60000", "-o", "report.tsv",
+          "--log_file_path", "fq.log", "--verbose"])
+    assert open("report.tsv", "rb").read() == (REFDATA / "reference_report_fastq.tsv").read_bytes()
+    log = open("fq.log").read()
+    assert "[mash sketch] Estimated genome size: 48454.7" in log and "[mash dist] mash dist" in log
+    # .github/workflows/test.yaml:69-77
+    main(["tests/data/NC_001416.1.fasta.gz", "-r", "tests/data/ref_sketch.msh", "-c", "tests/data/clade_config.csv",
+          "--expected_genome_size", "40000", "60000", "-o", "report.tsv", "--log_file_path", "fa.log"])
+    assert open("report.tsv", "rb").read() == (REFDATA / "reference_report_fasta.tsv").read_bytes()
+    # negative invocations must fail (test.yaml:80-106)
+    with pytest.raises(FileNotFoundError):
+        main(["tests/data/nope.fq.gz", "-r", "tests/data/ref_sketch.msh", "-c", "tests/data/clade_config.csv", "--log_file_path", "x.log"])
+    with pytest.raises(ValueError):
+        main(["tests/data/ref_sketch.msh", "-r", "tests/data/ref_sketch.msh", "-c", "tests/data/clade_config.csv", "--log_file_path", "x.log"])
