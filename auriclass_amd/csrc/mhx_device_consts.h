@@ -6,12 +6,20 @@
 namespace mhx {
 
 // ---- tile geometry of the sketch kernel ------------------------------------------------
-constexpr int kTileBytes = 32768;                    // bytes of the stream one workgroup owns
+#ifndef MHX_TILE_BYTES
+#define MHX_TILE_BYTES 32768
+#endif
+constexpr int kTileBytes = MHX_TILE_BYTES;           // bytes of the stream one workgroup owns
 constexpr int kHaloBytes = 64;                       // staged beyond the tile (>= 8 + 32)
-constexpr int kBlock = 256;                          // threads per workgroup (4 waves)
+#ifndef MHX_BLOCK
+#define MHX_BLOCK 256
+#endif
+constexpr int kBlock = MHX_BLOCK;                    // threads per workgroup
 constexpr int kGroup = 8;                            // k-mer start positions per work item
 constexpr int kGroupsPerTile = kTileBytes / kGroup;  // 4096
 constexpr int kBytesPerThread = kTileBytes / kBlock; // 128
+constexpr int kWordsPerThread = kBytesPerThread / 32; // 32-byte words classified per thread
+static_assert(kBytesPerThread % 32 == 0 && kTileBytes % (16 * kBlock) == 0, "tile geometry");
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // vacant slot of the candidate table
 
@@ -28,7 +36,8 @@ enum Stat : int {
     kStatMaxKey = 4,  // occurrences of the hash value 2^64-1 (cannot live in the table)
     kStatOccupied = 5,
     kStatSolid = 6,   // entries <= T with count >= m seen by the last tighten pass
-    kStatCount = 8
+    kStatStamp0 = 8,  // diagnostic builds (-DMHX_STAMPS): cycles per phase, summed over workgroups
+    kStatCount = 16
 };
 constexpr int kStatReplicas = 64; // counters are replicated to spread atomic traffic
 

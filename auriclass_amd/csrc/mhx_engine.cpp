@@ -414,6 +414,23 @@ extern "C" int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8)
     return MHX_OK;
 }
 
+// diagnostic: raw per-phase cycle sums of a -DMHX_STAMPS build (zeros otherwise)
+extern "C" int mhx_sketcher_debug_stamps(mhx_sketcher *sk, uint64_t *out8)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !out8) return fail(MHX_E_ARG, "null argument");
+    std::vector<uint64_t> h(kStatReplicas * kStatCount);
+    HIPCHK(hipMemcpyAsync(h.data(), sk->d_stats, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < 8; ++i) {
+        out8[i] = 0;
+        for (int r = 0; r < kStatReplicas; ++r) out8[i] += h[r * kStatCount + kStatStamp0 + i];
+    }
+    return MHX_OK;
+}
+
 extern "C" int mhx_sketcher_threshold(mhx_sketcher *sk, uint64_t *threshold)
 {
     clear_error();

@@ -110,6 +110,30 @@ __device__ uint32_t lookback_wave(uint64_t *state, uint32_t tile, uint32_t first
     return excl;
 }
 
+// exclusive prefix sum over the workgroup's threads (wave shuffles + 4 partials through LDS);
+// every thread also gets the workgroup total.  One barrier.
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t value, uint32_t *wave_sums, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = value;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) wave_sums[wave] = v;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        const uint32_t x = wave_sums[w];
+        if (w < wave) base += x;
+        all += x;
+    }
+    total = all;
+    return base + v - value;
+}
+
 // ---------------------------------------------------------------------------------------
 template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_kernel(const HashArgs a)
 {
@@ -129,20 +153,33 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_
     const uint64_t tile_off = (uint64_t)tile * kTileBytes;
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(a.stats) + (tile % kStatReplicas) * kStatCount;
     if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; }
+#ifdef MHX_STAMPS
+    uint64_t stamp_prev = clock64();
+    int stamp_idx = 0;
+#define MHX_STAMP()                                                                                      \
+    do {                                                                                                 \
+        if (tid == 0) {                                                                                  \
+            const uint64_t now_ = clock64();                                                             \
+            atomicAdd(&stats[kStatStamp0 + stamp_idx], (unsigned long long)(now_ - stamp_prev));         \
+            stamp_prev = now_;                                                                           \
+        }                                                                                                \
+        ++stamp_idx;                                                                                     \
+    } while (0)
+#else
+#define MHX_STAMP() do { } while (0)
+#endif
 
     phase_stage(sm, tid, a.base, tile_off, a.end);
     __syncthreads();
+    MHX_STAMP(); // 0: stage (global loads -> LDS)
 
     ThreadState st;
     phase_classify<FASTQ>(sm, tid, st, tile_off, a.begin, a.end);
 
+    MHX_STAMP(); // 1: classify
     uint32_t line_base = 0, excl = 0, tile_total = 0;
     if (FASTQ) {
-        __syncthreads();
-        excl = prefix_cnt(sm, tid);
-        if (tid == kBlock - 1) sm.misc[5] = excl + st.nlcount;
-        __syncthreads();
-        tile_total = sm.misc[5];
+        excl = block_scan_excl(st.nlcount, sm.cnt, tile_total);
         if (tid < 64) {
             const uint32_t lb = lookback_wave(a.tile_state, tile, a.first_tile, tile_total, stats);
             if (tid == 0) sm.misc[0] = lb;
@@ -150,6 +187,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_
         __syncthreads();
         line_base = sm.misc[0];
     }
+    MHX_STAMP(); // 2: newline scan + look-back
     bool bad = false;
     // the format look-ahead may only read staged bytes that belong to the span
     const uint64_t span_left = a.end > tile_off ? a.end - tile_off : 0;
@@ -157,21 +195,24 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_
     phase_good<FASTQ>(sm, tid, st, line_base, excl, tile_total, check_limit, bad);
     if (FASTQ && bad) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagBadFastq);
     __syncthreads();
+    MHX_STAMP(); // 3: good-base map
 
-    const uint32_t kmers = phase_runs<K>(sm, tid);
+    uint32_t items = 0;
+    const uint32_t kmers = phase_runs<K>(sm, tid, items);
     if (kmers) atomicAdd(&sm.misc[3], kmers);
+    uint32_t nitems = 0;
+    const uint32_t items_before = block_scan_excl(items, sm.cnt + 8, nitems); // barrier inside: sm.valid complete
+    phase_compact(sm, tid, items_before);
     __syncthreads();
+    MHX_STAMP(); // 4: valid starts + work list
 
-    phase_compact(sm, tid, prefix_cnt(sm, tid));
-    __syncthreads();
-
-    const uint32_t nitems = sm.misc[1];
     const uint64_t T = *a.thresh;
     DeviceInserter ins{reinterpret_cast<unsigned long long *>(a.keys), a.cnts, a.slot_mask, stats};
     uint32_t ninsert = 0;
     for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K>(sm, sm.list[it], T, a.hash32 != 0, ins);
     if (ninsert) atomicAdd(&sm.misc[4], ninsert);
     __syncthreads();
+    MHX_STAMP(); // 5: work loop
     if (tid == 0) {
         if (sm.misc[3]) atomicAdd(&stats[kStatKmers], (unsigned long long)sm.misc[3]);
         if (sm.misc[4]) atomicAdd(&stats[kStatInserts], (unsigned long long)sm.misc[4]);

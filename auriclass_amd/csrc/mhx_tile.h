@@ -33,13 +33,13 @@ struct TileSmem {
     uint32_t good[(kTileBytes + kHaloBytes) / 32 + 2]; // 1 bit per byte: usable base
     uint32_t valid[kGroupsPerTile / 4];                // byte g = valid-start mask of group g
     uint16_t list[kGroupsPerTile];                     // compacted work list (group ids)
-    uint32_t cnt[kBlock];                              // per-thread counts for the prefix sums
+    uint32_t cnt[16];                                  // wave partials of the two workgroup scans
     uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
 };
 
 // per-thread state carried between phases (registers on the GPU)
 struct ThreadState {
-    uint32_t nl[4], acgt[4];       // masks of this thread's four 32-byte words
+    uint32_t nl[kWordsPerThread], acgt[kWordsPerThread]; // masks of this thread's 32-byte words
     uint32_t hnl[2], hacgt[2];     // thread 0 only: the two halo words
     uint32_t nlcount;
 };
@@ -69,9 +69,24 @@ MHX_HD uint32_t base_codes(uint32_t u) { return ((u >> 1) & 0x03030303u) ^ ((u >
 constexpr uint32_t kLutFwd = 0x54474341u;  // code -> 'A','C','G','T'
 constexpr uint32_t kLutComp = 0x41434754u; // code -> complement 'T','G','C','A'
 
+// low 32 bits of {hi:lo} >> (8 * byte_shift), byte_shift in 0..3.  On the device this must be
+// the v_alignbyte/v_alignbit instruction itself: written as a C shift-or, LLVM turns the
+// pattern into an unaligned load from a stack copy of the register array (scratch traffic).
 MHX_HD uint32_t funnel(uint32_t hi, uint32_t lo, int byte_shift)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)byte_shift);
+#else
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * byte_shift));
+#endif
+}
+MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
+{ // bit_shift in 0..31
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, bit_shift);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> bit_shift);
+#endif
 }
 
 // newline and A/C/G/T masks of one 32-byte word (8 dwords at p)
@@ -126,43 +141,45 @@ MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_byt
     return m;
 }
 
-// bit p of the result is set iff bits p..p+K-1 of the 160-bit window w[0..4] are all set
-// (only the low 128 result bits are returned).  R_{2n} = R_n & (R_n >> n); R_{n+1} = R_n & (w >> n).
-template <int K> MHX_HD void run_starts(const uint32_t (&w)[5], uint32_t (&out)[4])
+// bit p of the result is set iff bits p..p+K-1 of the window w[0..NWD] are all set (the
+// last word is look-ahead only; NWD result words are returned).
+// R_{2n} = R_n & (R_n >> n); R_{n+1} = R_n & (w >> n).
+template <int K, int NWD> MHX_HD void run_starts(const uint32_t (&w)[NWD + 1], uint32_t (&out)[NWD])
 {
-    uint32_t cur[5];
+    constexpr int N1 = NWD + 1;
+    uint32_t cur[N1];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) cur[i] = w[i];
+    for (int i = 0; i < N1; ++i) cur[i] = w[i];
     int len = 1;
     constexpr int top = K >= 32 ? 5 : K >= 16 ? 4 : K >= 8 ? 3 : K >= 4 ? 2 : K >= 2 ? 1 : 0;
 #pragma unroll
     for (int b = top - 1; b >= 0; --b) {
         // double
         {
-            uint32_t sh[5];
+            uint32_t sh[N1];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const uint32_t hi = (i + 1 < 5) ? cur[i + 1] : 0u;
-                sh[i] = len >= 32 ? hi : (uint32_t)(((((uint64_t)hi) << 32) | cur[i]) >> len);
+            for (int i = 0; i < N1; ++i) {
+                const uint32_t hi = (i + 1 < N1) ? cur[i + 1] : 0u;
+                sh[i] = (uint32_t)(((((uint64_t)hi) << 32) | cur[i]) >> len);
             }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) cur[i] &= sh[i];
+            for (int i = 0; i < N1; ++i) cur[i] &= sh[i];
             len *= 2;
         }
         if ((K >> b) & 1) {
-            uint32_t sh[5];
+            uint32_t sh[N1];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const uint32_t hi = (i + 1 < 5) ? w[i + 1] : 0u;
-                sh[i] = len >= 32 ? hi : (uint32_t)(((((uint64_t)hi) << 32) | w[i]) >> len);
+            for (int i = 0; i < N1; ++i) {
+                const uint32_t hi = (i + 1 < N1) ? w[i + 1] : 0u;
+                sh[i] = (uint32_t)(((((uint64_t)hi) << 32) | w[i]) >> len);
             }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) cur[i] &= sh[i];
+            for (int i = 0; i < N1; ++i) cur[i] &= sh[i];
             len += 1;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = cur[i];
+    for (int i = 0; i < NWD; ++i) out[i] = cur[i];
 }
 
 // ---- MurmurHash3_x64_128, seed 42, first 8 output bytes (mash getHash) ----------------
@@ -187,9 +204,9 @@ template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
         uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
         uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
         k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = ((h1 << 2) + h1) + 0x52dce729;
         k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = ((h2 << 2) + h2) + 0x38495ab5;
     }
     if (TAIL > 8) {
         uint64_t k2 = (uint64_t)w[(4 * NBLK + 2) & 7] | ((uint64_t)w[(4 * NBLK + 3) & 7] << 32);
@@ -237,7 +254,7 @@ MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile
     const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + tid * (kBytesPerThread / 4);
     uint32_t total = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kWordsPerThread; ++w) {
         uint32_t nl, ac;
         classify_word<FASTQ>(p + 8 * w, nl, ac);
         const uint32_t in = inrange_mask(tile_off + (uint64_t)tid * kBytesPerThread + 32u * w, begin, end);
@@ -257,19 +274,8 @@ MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile
             st.hacgt[w] = ac & in;
         }
     }
-    if (FASTQ) sm.cnt[tid] = total;
 }
 
-// exclusive prefix of sm.cnt over threads < tid (dumb broadcast reads; once per tile)
-MHX_HD uint32_t prefix_cnt(const TileSmem &sm, int tid)
-{
-    uint32_t s = 0;
-    const uint4 *c4 = reinterpret_cast<const uint4 *>(sm.cnt);
-    int i = 0;
-    for (; i + 4 <= tid; i += 4) { const uint4 v = c4[i / 4]; s += v.x + v.y + v.z + v.w; }
-    for (; i < tid; ++i) s += sm.cnt[i];
-    return s;
-}
 
 // P2c: good-base bits -> sm.good
 template <bool FASTQ>
@@ -279,13 +285,13 @@ MHX_HD void phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t li
     const uint8_t *tb = reinterpret_cast<const uint8_t *>(sm.bytes);
     uint32_t line = line_base + excl;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kWordsPerThread; ++w) {
         uint32_t g = st.acgt[w];
         if (FASTQ) {
             g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format);
             line += (uint32_t)__builtin_popcount(st.nl[w]);
         }
-        sm.good[tid * 4 + w] = g;
+        sm.good[tid * kWordsPerThread + w] = g;
     }
     if (tid == 0) {
         uint32_t hl = line_base + tile_total;
@@ -304,21 +310,22 @@ MHX_HD void phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t li
     }
 }
 
-// P3: valid k-mer starts of this thread's 128 positions -> sm.valid, #items -> sm.cnt
-template <int K> MHX_HD uint32_t phase_runs(TileSmem &sm, int tid)
+// P3: valid k-mer starts of this thread's positions -> sm.valid, #items -> sm.cnt
+template <int K> MHX_HD uint32_t phase_runs(TileSmem &sm, int tid, uint32_t &items_out)
 {
-    uint32_t w[5], v[4];
+    constexpr int NWD = kWordsPerThread;
+    uint32_t w[NWD + 1], v[NWD];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) w[i] = sm.good[tid * 4 + i];
-    run_starts<K>(w, v);
+    for (int i = 0; i < NWD + 1; ++i) w[i] = sm.good[tid * NWD + i];
+    run_starts<K, NWD>(w, v);
     uint32_t items = 0, kmers = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sm.valid[tid * 4 + i] = v[i];
+    for (int i = 0; i < NWD; ++i) {
+        sm.valid[tid * NWD + i] = v[i];
         kmers += (uint32_t)__builtin_popcount(v[i]);
         items += 4u - (uint32_t)__builtin_popcount(zero_byte_flags(v[i]));
     }
-    sm.cnt[tid] = items;
+    items_out = items;
     return kmers;
 }
 
@@ -327,13 +334,100 @@ MHX_HD void phase_compact(TileSmem &sm, int tid, uint32_t excl)
 {
     uint32_t pos = excl;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t v = sm.valid[tid * 4 + i];
+    for (int i = 0; i < kWordsPerThread; ++i) {
+        const uint32_t v = sm.valid[tid * kWordsPerThread + i];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            if ((v >> (8 * b)) & 0xFFu) sm.list[pos++] = (uint16_t)(tid * 16 + i * 4 + b);
+            if ((v >> (8 * b)) & 0xFFu) sm.list[pos++] = (uint16_t)((tid * kWordsPerThread + i) * 4 + b);
     }
     if (tid == kBlock - 1) sm.misc[1] = pos;
+}
+
+// ASCII complement of four folded bases at once: A<->T differ by 0x15, C<->G by 0x04, and
+// bit 1 tells the two pairs apart (A,T: 0; C,G: 1).
+MHX_HD uint32_t complement4(uint32_t u)
+{
+    const uint32_t m = (u >> 1) & 0x01010101u;
+    return u ^ 0x15151515u ^ (m | (m << 4));
+}
+
+// 64 bits starting at byte offset `off` (compile-time) of the dword array a
+template <int OFF, int N> MHX_HD uint64_t load64(const uint32_t (&a)[N])
+{
+    constexpr int q = OFF / 4, sh = OFF % 4;
+    static_assert(q + (sh ? 2 : 1) < N, "load64 out of range");
+    const uint32_t lo = sh ? funnel(a[q + 1], a[q], sh) : a[q];
+    const uint32_t hi = sh ? funnel(a[q + 2], a[q + 1], sh) : a[q + 1];
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// memcmp(fwd, rc, K) > 0, on the already extracted little-endian words (slow, exact)
+template <int NW> MHX_HD bool rc_is_smaller_full(const uint32_t (&wf)[8], const uint32_t (&wr)[8])
+{
+    bool rc_less = false, decided = false;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t a = __builtin_bswap32(wf[i]), b = __builtin_bswap32(wr[i]);
+        rc_less = decided ? rc_less : (b < a);
+        decided = decided || (a != b);
+    }
+    return rc_less;
+}
+
+// K bytes at byte offset OFF of the dword array src, as zero-padded little-endian words
+template <int K, int OFF, int N> MHX_HD void extract_words(const uint32_t (&src)[N], uint32_t (&w)[8])
+{
+    constexpr int NW = (K + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = i < NW ? funnel(src[OFF / 4 + i + 1], src[OFF / 4 + i], OFF % 4) : 0u;
+    if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+}
+
+// One window: canonical strand -> hash.  U = folded forward chunk, R = its reverse
+// complement, Wr = the forward chunk byte-reversed, Cc = the forward chunk complemented
+// (the last two only feed the strand decision).
+template <int K, int J, int ND>
+MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1], const uint32_t (&Wr)[ND + 1],
+                            const uint32_t (&Cc)[ND + 1])
+{
+    constexpr int NW = (K + 3) / 4;
+    constexpr int OF = J;               // forward window starts at U byte OF
+    constexpr int OR = ND * 4 - K - J;  // its reverse complement starts at R byte OR
+    uint32_t w[8];
+#ifndef MHX_STRAND_FAST
+#define MHX_STRAND_FAST 1
+#endif
+    if (MHX_STRAND_FAST && K >= 8) {
+        // memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most
+        // significant first, are 8 little-endian bytes of Wr resp. Cc.  Equal first 8 bases
+        // (4^-8 of the windows) fall back to the full comparison.
+        const uint64_t top_f = load64<ND * 4 - 8 - J>(Wr);
+        const uint64_t top_r = load64<J + K - 8>(Cc);
+        bool rc = top_r < top_f;
+        if (K > 8 && top_r == top_f) {
+            uint32_t wf[8], wr[8];
+            extract_words<K, OF>(U, wf);
+            extract_words<K, OR>(R, wr);
+            rc = rc_is_smaller_full<NW>(wf, wr);
+        }
+        // select the source dwords first, extract once
+        uint32_t S[NW + 1];
+#pragma unroll
+        for (int i = 0; i < NW + 1; ++i) S[i] = rc ? R[OR / 4 + i] : U[OF / 4 + i];
+        const uint32_t sh = rc ? 8u * (OR % 4) : 8u * (OF % 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            w[i] = i < NW ? funnel_bits(S[i + 1], S[i], sh) : 0u;
+        if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+    } else {
+        uint32_t wf[8], wr[8];
+        extract_words<K, OF>(U, wf);
+        extract_words<K, OR>(R, wr);
+        const bool rc = rc_is_smaller_full<NW>(wf, wr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = rc ? wr[i] : wf[i];
+    }
+    return murmur3_h1<K>(w);
 }
 
 // P5: one work item = 8 consecutive window starts sharing one register chunk.
@@ -343,56 +437,62 @@ MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool h
 {
     constexpr int NB = kGroup + K - 1; // bytes touched
     constexpr int ND = (NB + 3) / 4;   // dwords loaded
-    constexpr int NW = (K + 3) / 4;    // dwords of one k-mer
     const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
-    uint32_t U[ND + 1], R[ND + 1], C[ND];
+    uint32_t U[ND + 1], R[ND + 1], Wr[ND + 1], Cc[ND + 1];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         U[d] = src[d] & 0xDFDFDFDFu; // fold case: mash upper-cases before hashing
-        C[d] = base_codes(U[d]);
+        Cc[d] = complement4(U[d]);
     }
-    U[ND] = 0;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) R[d] = perm_lut(kLutComp, __builtin_bswap32(C[ND - 1 - d]));
-    R[ND] = 0;
-    uint32_t ninserted = 0;
+    for (int d = 0; d < ND; ++d) {
+        R[d] = __builtin_bswap32(Cc[ND - 1 - d]);
+        Wr[d] = __builtin_bswap32(U[ND - 1 - d]);
+    }
+    U[ND] = R[ND] = Wr[ND] = Cc[ND] = 0;
+    constexpr bool kHash32 = K <= 16; // mash keeps 32 bits when 4^k <= 2^32
+    (void)hash32;
+#ifndef MHX_BATCH_ADMIT
+#define MHX_BATCH_ADMIT 0
+#endif
+#if MHX_BATCH_ADMIT
+    // all eight hashes first (one straight-line block the scheduler can interleave), then ONE
+    // admission test: windows below the threshold are ~1e-4 of all, so the insert path is cold
+    uint64_t h[kGroup];
+    h[0] = window_hash<K, 0, ND>(U, R, Wr, Cc);
+    h[1] = window_hash<K, 1, ND>(U, R, Wr, Cc);
+    h[2] = window_hash<K, 2, ND>(U, R, Wr, Cc);
+    h[3] = window_hash<K, 3, ND>(U, R, Wr, Cc);
+    h[4] = window_hash<K, 4, ND>(U, R, Wr, Cc);
+    h[5] = window_hash<K, 5, ND>(U, R, Wr, Cc);
+    h[6] = window_hash<K, 6, ND>(U, R, Wr, Cc);
+    h[7] = window_hash<K, 7, ND>(U, R, Wr, Cc);
+    uint64_t lowest = ~0ull;
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
-        const int of = j;               // forward window starts at U byte `of`
-        const int orr = ND * 4 - K - j; // its reverse complement starts at R byte `orr`
-        uint32_t wf[8], wr[8], w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < NW) {
-                wf[i] = funnel(U[of / 4 + i + 1], U[of / 4 + i], of % 4);
-                wr[i] = funnel(R[orr / 4 + i + 1], R[orr / 4 + i], orr % 4);
-            } else {
-                wf[i] = 0;
-                wr[i] = 0;
-            }
-        }
-        if (K % 4) {
-            wf[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
-            wr[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
-        }
-        // memcmp(fwd, rc, K) <= 0 ? fwd : rc   (big-endian dword compare, first difference decides)
-        bool rc_less = false, decided = false;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const uint32_t a = __builtin_bswap32(wf[i]), b = __builtin_bswap32(wr[i]);
-            rc_less = decided ? rc_less : (b < a);
-            decided = decided || (a != b);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = rc_less ? wr[i] : wf[i];
-        uint64_t h = murmur3_h1<K>(w);
-        if (hash32) h &= 0xFFFFFFFFull;
-        if (((vm >> j) & 1u) && h <= T) {
-            ins(h);
-            ++ninserted;
-        }
+        if (kHash32) h[j] &= 0xFFFFFFFFull;
+        const uint64_t c = ((vm >> j) & 1u) ? h[j] : ~0ull;
+        lowest = c < lowest ? c : lowest;
     }
+    uint32_t ninserted = 0;
+    if (lowest <= T && vm) {
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            if (((vm >> j) & 1u) && h[j] <= T) { ins(h[j]); ++ninserted; }
+    }
+#else
+    uint32_t ninserted = 0;
+#define MHX_WINDOW(J)                                                    \
+    {                                                                    \
+        uint64_t h = window_hash<K, J, ND>(U, R, Wr, Cc);                \
+        if (kHash32) h &= 0xFFFFFFFFull;                                 \
+        if (((vm >> J) & 1u) && h <= T) { ins(h); ++ninserted; }         \
+    }
+    MHX_WINDOW(0) MHX_WINDOW(1) MHX_WINDOW(2) MHX_WINDOW(3) MHX_WINDOW(4) MHX_WINDOW(5) MHX_WINDOW(6) MHX_WINDOW(7)
+#undef MHX_WINDOW
+#endif
+    static_assert(kGroup == 8, "process_group unrolls 8 windows");
     return ninserted;
 }
 

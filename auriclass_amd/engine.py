@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libmhx.so"
+LIB_PATH = Path(os.environ.get("MHX_LIB", _PKG / "lib" / "libmhx.so"))  # MHX_LIB: experiment builds
 HEADER_PATH = _PKG.parent / "include" / "mhx.h"
 
 MHX_OK = 0

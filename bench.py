@@ -51,14 +51,21 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; MHX_DIST_BACKEND=gloo lets several ranks rehearse on a 1-GPU box
+    backend = os.environ.get("MHX_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    engine.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    engine.init(dev_index)
 
     # ---- synthetic input, resident in HBM before anything is timed -------------------------
     genome = synth.make_genome(args.genome, seed=42)
@@ -75,7 +82,7 @@ def main() -> None:
         if world == 1:
             return sk.finish()
         t = sk.threshold()
-        return multigpu.exchange_and_merge(t, sk.export, args.s, args.m, engine.merge_partials, dev)
+        return multigpu.exchange_and_merge(t, sk.export, args.s, args.m, engine.merge_partials, comm_dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -92,7 +99,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3

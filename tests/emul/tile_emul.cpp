@@ -31,9 +31,8 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         for (int t = 0; t < kBlock; ++t) phase_stage(sm, t, base, tile_off, end);
         for (int t = 0; t < kBlock; ++t) phase_classify<FASTQ>(sm, t, st[t], tile_off, begin, end);
         uint32_t excl[kBlock] = {0}, tile_total = 0;
-        if (FASTQ) {
-            for (int t = 0; t < kBlock; ++t) excl[t] = prefix_cnt(sm, t);
-            tile_total = excl[kBlock - 1] + st[kBlock - 1].nlcount;
+        if (FASTQ) { // the kernel's block_scan_excl
+            for (int t = 0; t < kBlock; ++t) { excl[t] = tile_total; tile_total += st[t].nlcount; }
         }
         const uint32_t line_base = line_prefix; // what the look-back returns
         line_prefix += tile_total;
@@ -42,9 +41,8 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
         for (int t = 0; t < kBlock; ++t) phase_good<FASTQ>(sm, t, st[t], line_base, excl[t], tile_total, check_limit, bad);
         if (bad) stats[kStatFlags] |= kFlagBadFastq;
-        for (int t = 0; t < kBlock; ++t) stats[kStatKmers] += phase_runs<K>(sm, t);
-        uint32_t ex2[kBlock];
-        for (int t = 0; t < kBlock; ++t) ex2[t] = prefix_cnt(sm, t);
+        uint32_t ex2[kBlock], run = 0;
+        for (int t = 0; t < kBlock; ++t) { uint32_t items = 0; stats[kStatKmers] += phase_runs<K>(sm, t, items); ex2[t] = run; run += items; }
         for (int t = 0; t < kBlock; ++t) phase_compact(sm, t, ex2[t]);
         const uint32_t nitems = sm.misc[1];
         for (uint32_t it = 0; it < nitems; ++it) stats[kStatInserts] += process_group<K>(sm, sm.list[it], T, hash32, ins);

@@ -142,3 +142,34 @@ def test_empty_and_tiny(emul):
     for data in (b"", b"A", b"ACGTACGTACGTACGTACGT", b"ACGTACGTACGTACGTACGTA"):
         got, _ = run_emul(emul, data, 21, fmt=0)
         assert np.array_equal(got, oracle_hashes([data], 21))
+
+
+def palindromic_edge_reads(rng, k, n):
+    """Windows whose first 8 bases equal the first 8 bases of their reverse complement, so the
+    strand decision falls through the fast 8-base comparison into the exact one."""
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    out = []
+    for _ in range(n):
+        x = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=8)
+        mid = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=max(0, k - 16))
+        kmer = np.concatenate([x, mid, np.array([comp[int(c)] for c in x[::-1]], np.uint8)])[:k] if k >= 16 else None
+        if kmer is None:      # 8 < k < 16: overlap the two ends
+            kmer = np.concatenate([x, np.array([comp[int(c)] for c in x[::-1]], np.uint8)[16 - k:]])
+            # make the overlapping part self-consistent: retry until first 8 == rc first 8
+            rc = np.array([comp[int(c)] for c in kmer[::-1]], np.uint8)
+            if not np.array_equal(kmer[:8], rc[:8]):
+                continue
+        flank_l = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 12)))
+        flank_r = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 12)))
+        out.append(bytes(np.concatenate([flank_l, kmer, flank_r])))
+    return out
+
+
+@pytest.mark.parametrize("k", [16, 17, 20, 21, 24, 27, 31, 32])
+def test_strand_decision_fallback_branch(emul, k):
+    rng = np.random.default_rng(900 + k)
+    reads = palindromic_edge_reads(rng, k, 3000)
+    assert len(reads) > 20
+    data = b"\n".join(reads) + b"\n"
+    got, _ = run_emul(emul, data, k, fmt=0)
+    assert np.array_equal(got, oracle_hashes(reads, k))
