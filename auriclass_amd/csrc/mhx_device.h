@@ -54,4 +54,17 @@ struct DistArgs {
 };
 hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st);
 
+// all-vs-refs fast path (nr <= 32): value-range partition + LDS hash probe
+constexpr int kDistRanges = 512;      // value ranges the hash space is cut into
+constexpr int kDistTableSlots = 4096; // LDS table of one range (refs' hashes of that range)
+constexpr int kDistQueryChunks = 4;   // query chunks per range (grid.y of the range kernel)
+struct DistWork {
+    uint32_t *offs_q;   // [nq][kDistRanges + 1] first index of every range in each query list
+    uint32_t *offs_r;   // [nr][kDistRanges + 1]
+    uint16_t *cpart;    // [kDistRanges][nq][nr] shared hashes per (range, query, ref)
+    uint32_t *params;   // [0] shift, [1] overflow flag
+};
+size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, size_t *off_c, size_t *off_p);
+hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t st);
+
 } // namespace mhx

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 
@@ -46,6 +47,8 @@ struct Engine {
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_dist_ms = 0.0;
+    uint8_t *dist_ws = nullptr; // workspace of the all-vs-refs distance path
+    size_t dist_ws_cap = 0;
 };
 static Engine g;
 
@@ -85,6 +88,7 @@ extern "C" void mhx_shutdown(void)
 {
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
+    hipFree(g.dist_ws);
     hipEventDestroy(g.ev0);
     hipEventDestroy(g.ev1);
     hipStreamDestroy(g.stream);
@@ -614,8 +618,31 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         a.q = (const uint64_t *)dq; a.q_len = (const uint32_t *)dql; a.r = (const uint64_t *)dr; a.r_len = (const uint32_t *)drl;
         a.common = (uint32_t *)dc; a.denom = (uint32_t *)dd; a.dist = nullptr; // distances in host libm below
     }
+    // all-vs-refs fast path when the reference set fits one 32-bit mask; the generic
+    // pair-per-workgroup kernel otherwise, and as the fallback for non-uniform value ranges
+    const bool fast = nr <= 32 && pairs >= 64 && getenv("MHX_DIST_GENERIC") == nullptr;
+    DistWork w{};
+    if (fast) {
+        size_t oq, orr, oc, op;
+        const size_t need = dist_work_bytes(nq, nr, &oq, &orr, &oc, &op);
+        if (g.dist_ws_cap < need) {
+            hipFree(g.dist_ws);
+            g.dist_ws = nullptr;
+            g.dist_ws_cap = 0;
+            if (hipMalloc((void **)&g.dist_ws, need) != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "hipMalloc failed for the distance workspace"); }
+            g.dist_ws_cap = need;
+        }
+        w.offs_q = (uint32_t *)(g.dist_ws + oq); w.offs_r = (uint32_t *)(g.dist_ws + orr);
+        w.cpart = (uint16_t *)(g.dist_ws + oc); w.params = (uint32_t *)(g.dist_ws + op);
+    }
     hipEventRecord(g.ev0, g.stream);
-    hipError_t le = launch_dist_pairs(a, g.stream);
+    hipError_t le = fast ? launch_dist_ranges(a, w, g.stream) : launch_dist_pairs(a, g.stream);
+    if (le == hipSuccess && fast) {
+        uint32_t flag = 0;
+        hipMemcpyAsync(&flag, w.params + 1, 4, hipMemcpyDeviceToHost, g.stream);
+        hipStreamSynchronize(g.stream);
+        if (flag) le = launch_dist_pairs(a, g.stream); // a value range overflowed the LDS table
+    }
     hipEventRecord(g.ev1, g.stream);
     if (le != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le)); }
     if (!device_ptrs) {

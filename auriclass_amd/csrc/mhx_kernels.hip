@@ -437,4 +437,189 @@ hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// All-vs-refs distance, fast path.  Hash values are uniform, so cutting the value space into
+// 512 equal ranges cuts every sorted list into 512 short, aligned sub-lists (offsets by
+// binary search).  For one range, ALL references' hashes (<= 32 refs) go into one LDS hash
+// table: key -> bit mask of the references that contain it.  Every query element is then
+// probed ONCE and yields its shared-hash bits for all references at the same time (ballot +
+// popcount per reference), instead of being merged 24 times.  A last kernel walks the
+// per-range counts of each (query, ref) pair to the range where the union reaches s and
+// finishes that one short range exactly with the sequential two-pointer rule.
+// ---------------------------------------------------------------------------------------
+__global__ void dist_shift_kernel(const DistArgs a, DistWork w)
+{
+    __shared__ unsigned long long gmax;
+    if (threadIdx.x == 0) gmax = 0;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (uint32_t i = threadIdx.x; i < a.nq + a.nr; i += blockDim.x) {
+        const bool isq = i < a.nq;
+        const uint32_t li = isq ? i : i - a.nq;
+        const uint32_t n = isq ? a.q_len[li] : a.r_len[li];
+        if (n) {
+            const uint64_t v = (isq ? a.q : a.r)[(uint64_t)li * a.stride + n - 1];
+            m = v > m ? v : m;
+        }
+    }
+    atomicMax(&gmax, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int bits = gmax ? 64 - __builtin_clzll(gmax) : 1;
+        const int lg = 31 - __builtin_clz((unsigned)kDistRanges);
+        w.params[0] = bits > lg ? bits - lg : 0; // value >> shift is a range index < kDistRanges
+        w.params[1] = 0;
+    }
+}
+
+__global__ void dist_split_kernel(const DistArgs a, DistWork w)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = kDistRanges + 1;
+    if (id >= (a.nq + a.nr) * per) return;
+    const uint32_t list = id / per, p = id % per;
+    const bool isq = list < a.nq;
+    const uint32_t li = isq ? list : list - a.nq;
+    const uint32_t n = isq ? a.q_len[li] : a.r_len[li];
+    const uint64_t *v = (isq ? a.q : a.r) + (uint64_t)li * a.stride;
+    const uint32_t shift = w.params[0];
+    uint32_t lo = 0, hi = n;
+    if (p == kDistRanges) lo = n;
+    else {
+        while (lo < hi) { // first element whose range index is >= p
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((v[mid] >> shift) < p) lo = mid + 1; else hi = mid;
+        }
+    }
+    (isq ? w.offs_q : w.offs_r)[li * per + p] = lo;
+}
+
+__global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistWork w)
+{
+    __shared__ unsigned long long keys[kDistTableSlots];
+    __shared__ uint32_t masks[kDistTableSlots];
+    __shared__ uint32_t too_big;
+    const uint32_t p = blockIdx.x, per = kDistRanges + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < kDistTableSlots; i += 256) { keys[i] = kEmptyKey; masks[i] = 0; }
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (uint32_t r = 0; r < a.nr; ++r) tot += w.offs_r[r * per + p + 1] - w.offs_r[r * per + p];
+        too_big = tot > (kDistTableSlots * 3) / 4;
+        if (too_big) atomicOr(&w.params[1], 1u);
+    }
+    __syncthreads();
+    if (too_big) return; // non-uniform input: the host reruns the generic kernel
+    auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 52) & (kDistTableSlots - 1); };
+    for (uint32_t r = 0; r < a.nr; ++r) {
+        const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
+        const uint64_t *v = a.r + (uint64_t)r * a.stride;
+        for (uint32_t i = b + tid; i < e; i += 256) {
+            const uint64_t x = v[i];
+            uint32_t sl = slot_of(x);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)x);
+                if (prev == kEmptyKey || prev == x) { atomicOr(&masks[sl], 1u << r); break; }
+                sl = (sl + 1) & (kDistTableSlots - 1);
+            }
+        }
+    }
+    __syncthreads();
+    // queries of this block's chunk, one wave per query at a time
+    const uint32_t qper = (a.nq + gridDim.y - 1) / gridDim.y;
+    const uint32_t q0 = blockIdx.y * qper, q1 = min(a.nq, q0 + qper);
+    for (uint32_t q = q0 + wave; q < q1; q += 4) {
+        const uint32_t b = w.offs_q[q * per + p], e = w.offs_q[q * per + p + 1];
+        const uint64_t *v = a.q + (uint64_t)q * a.stride;
+        uint32_t acc = 0; // lane r accumulates the count for reference r
+        for (uint32_t i0 = b; i0 < e; i0 += 64) {
+            uint32_t m = 0;
+            if (i0 + lane < e) {
+                const uint64_t x = v[i0 + lane];
+                uint32_t sl = slot_of(x);
+                for (;;) {
+                    const unsigned long long kx = keys[sl];
+                    if (kx == x) { m = masks[sl]; break; }
+                    if (kx == kEmptyKey) break;
+                    sl = (sl + 1) & (kDistTableSlots - 1);
+                }
+            }
+            for (uint32_t r = 0; r < a.nr; ++r) {
+                const uint32_t c = (uint32_t)__builtin_popcountll(__ballot((m >> r) & 1u));
+                acc += (lane == (int)r) ? c : 0u;
+            }
+        }
+        if (lane < (int)a.nr) w.cpart[((uint64_t)p * a.nq + q) * a.nr + lane] = (uint16_t)acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, DistWork w)
+{
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x; // pair = q * nr + r: lanes of a wave share q's data
+    if (pair >= a.nq * a.nr) return;
+    const uint32_t q = pair / a.nr, r = pair % a.nr, per = kDistRanges + 1;
+    const uint32_t *oq = w.offs_q + q * per, *orr = w.offs_r + r * per;
+    const uint32_t nA = a.r_len[r], nB = a.q_len[q], S = a.s;
+    uint32_t uni = 0, common = 0, p = 0;
+    for (; p < kDistRanges; ++p) {
+        const uint32_t c = w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
+        const uint32_t u = (orr[p + 1] - orr[p]) + (oq[p + 1] - oq[p]) - c;
+        if (uni + u >= S) break; // the s-th union element lies in this range
+        uni += u;
+        common += c;
+    }
+    uint32_t denom;
+    if (p == kDistRanges) denom = uni; // union smaller than s: everything counts
+    else {
+        // finish range p with the sequential rule until the union count reaches S
+        const uint64_t *A = a.r + (uint64_t)r * a.stride, *B = a.q + (uint64_t)q * a.stride;
+        uint32_t i = orr[p], j = oq[p];
+        const uint32_t ie = orr[p + 1], je = oq[p + 1];
+        while (uni < S && i < ie && j < je) {
+            const uint64_t x = A[i], y = B[j];
+            if (x < y) ++i;
+            else if (y < x) ++j;
+            else { ++i; ++j; ++common; }
+            ++uni;
+        }
+        denom = S; // uni + remaining of this range >= S by construction
+    }
+    (void)nA; (void)nB;
+    a.common[pair] = common;
+    a.denom[pair] = denom;
+    if (a.dist) {
+        double d;
+        if (common == denom) d = 0.0;
+        else if (common == 0) d = 1.0;
+        else {
+            const double jac = (double)common / (double)denom;
+            d = -log(2.0 * jac / (1.0 + jac)) / (double)a.k;
+            if (d > 1.0) d = 1.0;
+        }
+        a.dist[pair] = d;
+    }
+}
+
+size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, size_t *off_c, size_t *off_p)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    *off_q = o; o += up((size_t)nq * (kDistRanges + 1) * 4);
+    *off_r = o; o += up((size_t)nr * (kDistRanges + 1) * 4);
+    *off_c = o; o += up((size_t)kDistRanges * nq * nr * 2);
+    *off_p = o; o += 256;
+    return o;
+}
+
+hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t st)
+{
+    hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
+    const uint32_t n = (a.nq + a.nr) * (kDistRanges + 1);
+    hipLaunchKernelGGL(dist_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, w);
+    hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
+    const uint32_t pairs = a.nq * a.nr;
+    hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, a, w);
+    return hipGetLastError();
+}
+
 } // namespace mhx
