@@ -494,6 +494,26 @@ __global__ void dist_split_kernel(const DistArgs a, DistWork w)
     (isq ? w.offs_q : w.offs_r)[li * per + p] = lo;
 }
 
+// v_writelane_b32: lane R of `acc` := wave-uniform `value` (no clang builtin on this toolchain)
+template <int R> __device__ __forceinline__ void write_lane(uint32_t &acc, uint32_t value)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(value), "n"(R));
+#else
+    (void)acc; (void)value;
+#endif
+}
+// shared-hash counts of one wave-load of query elements: lane r gets the count for reference r
+template <int R> __device__ __forceinline__ void tally_refs(uint32_t &it, uint32_t m, uint32_t nr)
+{
+    if constexpr (R < 32) {
+        if (R < (int)nr) {
+            write_lane<R>(it, (uint32_t)__builtin_popcountll(__ballot(m & (1u << R))));
+            tally_refs<R + 1>(it, m, nr);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistWork w)
 {
     __shared__ unsigned long long keys[kDistTableSlots];
@@ -510,68 +530,125 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
     }
     __syncthreads();
     if (too_big) return; // non-uniform input: the host reruns the generic kernel
-    auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 52) & (kDistTableSlots - 1); };
-    for (uint32_t r = 0; r < a.nr; ++r) {
-        const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
-        const uint64_t *v = a.r + (uint64_t)r * a.stride;
-        for (uint32_t i = b + tid; i < e; i += 256) {
-            const uint64_t x = v[i];
-            uint32_t sl = slot_of(x);
-            for (;;) {
-                const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)x);
-                if (prev == kEmptyKey || prev == x) { atomicOr(&masks[sl], 1u << r); break; }
-                sl = (sl + 1) & (kDistTableSlots - 1);
+    auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
+    // build: wave w inserts references w, w+4, ...; a reference's slice of this range is a
+    // few dozen hashes, so all slices of the wave are loaded first, then inserted
+    {
+        constexpr int G = 8; // 32 references / 4 waves
+        uint64_t x[G];
+        bool have[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t r = wave + 4 * g;
+            have[g] = false;
+            if (r < a.nr) {
+                const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
+                if (b + lane < e) { x[g] = a.r[(uint64_t)r * a.stride + b + lane]; have[g] = true; }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t r = wave + 4 * g;
+            if (r >= a.nr) continue;
+            const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
+            for (uint32_t i = b + lane; i < e; i += 64) {
+                const uint64_t v = (i == b + lane && have[g]) ? x[g] : a.r[(uint64_t)r * a.stride + i];
+                uint32_t sl = slot_of(v);
+                for (;;) {
+                    const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
+                    if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
+                    sl = (sl + 1) & (kDistTableSlots - 1);
+                }
             }
         }
     }
     __syncthreads();
-    // queries of this block's chunk, one wave per query at a time
+    // probe: wave w takes queries q0+w, q0+w+4, ... of this block's chunk, 8 at a time so that
+    // eight global loads are in flight per lane; each query element is looked up once and
+    // its reference mask is tallied per reference by ballot + popcount (lane r keeps ref r)
     const uint32_t qper = (a.nq + gridDim.y - 1) / gridDim.y;
     const uint32_t q0 = blockIdx.y * qper, q1 = min(a.nq, q0 + qper);
-    for (uint32_t q = q0 + wave; q < q1; q += 4) {
-        const uint32_t b = w.offs_q[q * per + p], e = w.offs_q[q * per + p + 1];
-        const uint64_t *v = a.q + (uint64_t)q * a.stride;
-        uint32_t acc = 0; // lane r accumulates the count for reference r
-        for (uint32_t i0 = b; i0 < e; i0 += 64) {
-            uint32_t m = 0;
-            if (i0 + lane < e) {
-                const uint64_t x = v[i0 + lane];
-                uint32_t sl = slot_of(x);
-                for (;;) {
-                    const unsigned long long kx = keys[sl];
-                    if (kx == x) { m = masks[sl]; break; }
-                    if (kx == kEmptyKey) break;
-                    sl = (sl + 1) & (kDistTableSlots - 1);
-                }
-            }
-            for (uint32_t r = 0; r < a.nr; ++r) {
-                const uint32_t c = (uint32_t)__builtin_popcountll(__ballot((m >> r) & 1u));
-                acc += (lane == (int)r) ? c : 0u;
-            }
+    constexpr int G = 8;
+    for (uint32_t qb = q0 + wave; qb < q1; qb += 4 * G) {
+        uint64_t x[G];
+        uint32_t bb[G], ee[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t q = qb + 4 * g;
+            bb[g] = ee[g] = 0;
+            if (q < q1) { bb[g] = w.offs_q[q * per + p]; ee[g] = w.offs_q[q * per + p + 1]; }
         }
-        if (lane < (int)a.nr) w.cpart[((uint64_t)p * a.nq + q) * a.nr + lane] = (uint16_t)acc;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            x[g] = kEmptyKey;
+            if (bb[g] + lane < ee[g]) x[g] = a.q[(uint64_t)(qb + 4 * g) * a.stride + bb[g] + lane];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t q = qb + 4 * g;
+            if (q >= q1) break;
+            uint32_t acc = 0;
+            for (uint32_t i0 = bb[g]; i0 < ee[g]; i0 += 64) {
+                uint32_t m = 0;
+                if (i0 + lane < ee[g]) {
+                    const uint64_t v = i0 == bb[g] ? x[g] : a.q[(uint64_t)q * a.stride + i0 + lane];
+                    uint32_t sl = slot_of(v);
+                    for (;;) {
+                        const unsigned long long kx = keys[sl];
+                        if (kx == v) { m = masks[sl]; break; }
+                        if (kx == kEmptyKey) break;
+                        sl = (sl + 1) & (kDistTableSlots - 1);
+                    }
+                }
+                // per reference: one compare (-> SGPR mask), scalar popcount, one lane write
+                uint32_t it = 0;
+                tally_refs<0>(it, m, a.nr);
+                acc += it;
+            }
+            if (lane < (int)a.nr) w.cpart[((uint64_t)p * a.nq + q) * a.nr + lane] = (uint16_t)acc;
+        }
     }
 }
 
+// 16 pairs per workgroup; thread (seg, pair) first sums its 64 ranges, then the 16 threads of
+// segment 0 locate the cut segment, walk it range by range and finish the cut range with the
+// sequential two-pointer rule.
 __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, DistWork w)
 {
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x; // pair = q * nr + r: lanes of a wave share q's data
-    if (pair >= a.nq * a.nr) return;
-    const uint32_t q = pair / a.nr, r = pair % a.nr, per = kDistRanges + 1;
+    __shared__ uint32_t seg_uni[kDistSegs][16], seg_com[kDistSegs][16];
+    constexpr int RPS = kDistRanges / kDistSegs; // ranges per segment
+    const uint32_t pl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const uint32_t pair = blockIdx.x * 16 + pl;
+    const bool live = pair < a.nq * a.nr;
+    const uint32_t q = live ? pair / a.nr : 0, r = live ? pair % a.nr : 0, per = kDistRanges + 1;
     const uint32_t *oq = w.offs_q + q * per, *orr = w.offs_r + r * per;
-    const uint32_t nA = a.r_len[r], nB = a.q_len[q], S = a.s;
-    uint32_t uni = 0, common = 0, p = 0;
-    for (; p < kDistRanges; ++p) {
-        const uint32_t c = w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
-        const uint32_t u = (orr[p + 1] - orr[p]) + (oq[p + 1] - oq[p]) - c;
-        if (uni + u >= S) break; // the s-th union element lies in this range
-        uni += u;
-        common += c;
+    {
+        uint32_t com = 0;
+        for (uint32_t p = seg * RPS; p < (seg + 1) * RPS; ++p) com += w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
+        const uint32_t p0 = seg * RPS, p1 = (seg + 1) * RPS;
+        seg_com[seg][pl] = com;
+        seg_uni[seg][pl] = (orr[p1] - orr[p0]) + (oq[p1] - oq[p0]) - com;
+    }
+    __syncthreads();
+    if (seg != 0 || !live) return;
+    const uint32_t S = a.s;
+    uint32_t uni = 0, common = 0, sg = 0;
+    for (; sg < kDistSegs; ++sg) {
+        if (uni + seg_uni[sg][pl] >= S) break;
+        uni += seg_uni[sg][pl];
+        common += seg_com[sg][pl];
     }
     uint32_t denom;
-    if (p == kDistRanges) denom = uni; // union smaller than s: everything counts
+    if (sg == kDistSegs) denom = uni; // union smaller than s: everything counts
     else {
-        // finish range p with the sequential rule until the union count reaches S
+        uint32_t p = sg * RPS;
+        for (;; ++p) { // the cut range is inside this segment
+            const uint32_t c = w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
+            const uint32_t u = (orr[p + 1] - orr[p]) + (oq[p + 1] - oq[p]) - c;
+            if (uni + u >= S) break;
+            uni += u;
+            common += c;
+        }
         const uint64_t *A = a.r + (uint64_t)r * a.stride, *B = a.q + (uint64_t)q * a.stride;
         uint32_t i = orr[p], j = oq[p];
         const uint32_t ie = orr[p + 1], je = oq[p + 1];
@@ -582,9 +659,8 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
             else { ++i; ++j; ++common; }
             ++uni;
         }
-        denom = S; // uni + remaining of this range >= S by construction
+        denom = S; // this range holds enough further union elements by construction
     }
-    (void)nA; (void)nB;
     a.common[pair] = common;
     a.denom[pair] = denom;
     if (a.dist) {
@@ -618,7 +694,7 @@ hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t 
     hipLaunchKernelGGL(dist_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, w);
     hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
     const uint32_t pairs = a.nq * a.nr;
-    hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, a, w);
+    hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 15) / 16), dim3(256), 0, st, a, w);
     return hipGetLastError();
 }
 

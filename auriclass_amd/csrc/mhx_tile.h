@@ -397,14 +397,14 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
 #ifndef MHX_STRAND_FAST
 #define MHX_STRAND_FAST 1
 #endif
-    if (MHX_STRAND_FAST && K >= 8) {
+    if constexpr (MHX_STRAND_FAST && K >= 8) {
         // memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most
         // significant first, are 8 little-endian bytes of Wr resp. Cc.  Equal first 8 bases
         // (4^-8 of the windows) fall back to the full comparison.
         const uint64_t top_f = load64<ND * 4 - 8 - J>(Wr);
         const uint64_t top_r = load64<J + K - 8>(Cc);
         bool rc = top_r < top_f;
-        if (K > 8 && top_r == top_f) {
+        if (K > 8 && top_r == top_f) { // cold: exact comparison
             uint32_t wf[8], wr[8];
             extract_words<K, OF>(U, wf);
             extract_words<K, OR>(R, wr);

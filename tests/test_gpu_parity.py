@@ -247,3 +247,66 @@ def test_dist_batch_equals_oracle_compare():
             c, d, dd = mo.compare(r, q, s, k)
             assert (common[qi, ri], denom[qi, ri]) == (c, d), (qi, ri)
             assert dist[qi, ri] == dd
+
+
+def _pad_rows(lists, stride):
+    M = np.zeros((len(lists), stride), np.uint64)
+    for i, v in enumerate(lists):
+        M[i, :len(v)] = v
+    return M, np.array([len(v) for v in lists], np.uint32)
+
+
+def _check_all_pairs(qrys, refs, k, s):
+    stride = max(max(map(len, refs)), max(map(len, qrys)), 1)
+    Q, ql = _pad_rows(qrys, stride)
+    R, rl = _pad_rows(refs, stride)
+    common, denom, dist = engine.dist_batch(Q, ql, R, rl, k, s)
+    for qi, q in enumerate(qrys):
+        for ri, r in enumerate(refs):
+            c, d, dd = mo.compare(r, q, s, k)
+            assert (common[qi, ri], denom[qi, ri]) == (c, d), (qi, ri, len(q), len(r))
+            assert dist[qi, ri] == dd
+
+
+def _sketch_like(rng, n, hi=2 ** 64):
+    return np.unique(rng.integers(0, hi, size=n, dtype=np.uint64))
+
+
+def test_dist_all_vs_refs_fast_path_equals_oracle():
+    """C5-shaped, reduced: 40 queries x 24 refs, s = 6000 (all-vs-refs LDS path)."""
+    rng = np.random.default_rng(21)
+    s = 6000
+    base = _sketch_like(rng, s)
+    refs = []
+    for j in range(24):
+        keep = rng.random(len(base)) >= (0.002 * (j + 1) if j < 11 else 0.5)
+        refs.append(np.unique(np.concatenate([base[keep], _sketch_like(rng, int((~keep).sum()))])))
+    refs[3] = refs[3][:s - 900]                       # a reference shorter than s
+    qrys = []
+    for i in range(40):
+        src = refs[i % 24]
+        keep = rng.random(len(src)) >= 0.6 * i / 39
+        qrys.append(np.unique(np.concatenate([src[keep], _sketch_like(rng, int((~keep).sum()))])))
+    qrys[5] = refs[5].copy()
+    qrys[6] = qrys[6][:17]
+    qrys[7] = np.zeros(0, np.uint64)
+    _check_all_pairs(qrys, refs, 27, s)
+
+
+def test_dist_non_uniform_values_fall_back_to_the_generic_kernel():
+    """All hashes crowded into one narrow value range overflow the per-range LDS table; the
+    engine must notice and still return exact results (generic pair kernel)."""
+    rng = np.random.default_rng(22)
+    lo = 1 << 62
+    refs = [lo + _sketch_like(rng, 3000, hi=2 ** 20) for _ in range(8)]
+    refs.append(np.concatenate([refs[0][:1000], np.array([2 ** 64 - 5], np.uint64)]))   # one far outlier sets the scale
+    qrys = [np.unique(np.concatenate([refs[i % 8][::2], lo + _sketch_like(rng, 1500, hi=2 ** 20)])) for i in range(10)]
+    _check_all_pairs(qrys, refs, 21, 3000)
+
+
+def test_dist_more_than_32_refs_and_k16_32bit_hashes():
+    rng = np.random.default_rng(23)
+    refs = [_sketch_like(rng, 800, hi=2 ** 32) for _ in range(40)]
+    qrys = [np.unique(np.concatenate([refs[i][:400], _sketch_like(rng, 400, hi=2 ** 32)])) for i in range(6)]
+    _check_all_pairs(qrys, refs, 16, 800)
+    _check_all_pairs(qrys, refs[:24], 16, 800)          # fast path on 32-bit hash values
