@@ -11,10 +11,11 @@ from pathlib import Path
 
 src, dst, steps = Path(sys.argv[1]), sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 out = {}
-for f in glob.glob(str(src / "*" / "*" / "*_kernel_stats.csv")):
+for f in sorted(glob.glob(str(src / "*" / "*" / "*_kernel_stats.csv"))):
     lines = Path(f).read_text().splitlines()
     keep = [lines[0]] + [l for l in lines[1:] if "mhx::" in l or "rccl" in l.lower() or "nccl" in l.lower()]
-    Path(dst + "_kernel_stats.csv").write_text("\n".join(keep) + "\n")
+    tag = Path(f).parent.parent.name
+    Path(dst + "_kernel_stats_" + tag + ".csv").write_text("\n".join(keep) + "\n")
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.Counter()
 for f in glob.glob(str(src / "*" / "*" / "*_counter_collection.csv")):
