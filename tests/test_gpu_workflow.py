@@ -103,3 +103,32 @@ def test_cli_reports_are_byte_identical_to_the_reference_reports(refcwd):
         main(["tests/data/nope.fq.gz", "-r", "tests/data/ref_sketch.msh", "-c", "tests/data/clade_config.csv", "--log_file_path", "x.log"])
     with pytest.raises(ValueError):
         main(["tests/data/ref_sketch.msh", "-r", "tests/data/ref_sketch.msh", "-c", "tests/data/clade_config.csv", "--log_file_path", "x.log"])
+
+
+def test_mash_named_shim_serves_the_references_subprocess_calls(refcwd):
+    """What an unmodified AuriClass checkout does: subprocess.run(["mash", ...], PIPE, PIPE) with
+    the shim directory first on PATH (classes.py:92-104, 305-318, 576-596, 696-713; general.py:198-205)."""
+    import os
+    import subprocess
+    from pathlib import Path
+
+    import auriclass_amd
+
+    env = dict(os.environ)
+    env["PATH"] = str(Path(auriclass_amd.__file__).parent / "bin") + os.pathsep + env["PATH"]
+
+    def mash(*argv):
+        return subprocess.run(["mash", *argv], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+
+    assert mash("-h").returncode == 0
+    out = mash("sketch", "-r", "-m", "3", "-o", "q.msh", "-k", "27", "-s", "50000",
+               "tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz")
+    assert "Estimated genome size: 48454.7" in out.stderr.decode()
+    rows = mash("dist", "tests/data/ref_sketch.msh", "q.msh").stdout.decode()
+    assert rows == ("tests/data/NC_001416.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t9.55405e-06\t0\t48451/48476\n"
+                    "tests/data/NC_001604.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t1\t1\t0/50000\n")
+    assert mash("bounds", "-k", "27", "-p", "0.99").stdout.decode() == (GOLDEN / "mash_bounds_k27_p0.99.txt").read_text()
+    empty = mash("sketch", "-r", "-m", "3", "-o", "e.msh", "-k", "27", "-s", "50000", "tests/data/test_empty_1.fq.gz")
+    assert "ERROR: Did not find fasta records in" in empty.stderr.decode() and empty.returncode == 1
+    fa = mash("sketch", "-o", "ref2", "-k", "27", "-s", "50000", "tests/data/NC_001416.1.fasta", "tests/data/NC_001604.1.fasta")
+    assert fa.returncode == 0 and open("ref2.msh", "rb").read() == (REFDATA / "ref_sketch.msh").read_bytes()
