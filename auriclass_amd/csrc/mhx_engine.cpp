@@ -189,8 +189,11 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     // the bound was loose enough and reports MHX_E_CAPACITY otherwise.
     uint64_t T = sk->hash_max;
     if (sk->m > 1 && sk->expected_bytes > sk->nslots / 4) {
-        const long double frac = (long double)(sk->nslots / 4) / (long double)sk->expected_bytes;
-        T = (uint64_t)(frac * (long double)sk->hash_max);
+        // at most 256*s admissions over the whole expected input: stays exact up to ~256x
+        // coverage (the s-th qualifying hash sits near s/D for D distinct solid k-mers, and the
+        // input holds about coverage*D windows), and duplicates keep the table far emptier
+        const long double frac = (long double)(256.0L * sk->s) / (long double)sk->expected_bytes;
+        if (frac < 1.0L) T = (uint64_t)(frac * (long double)sk->hash_max);
     }
     sk->t_init = T;
     sk->last_T = T;
@@ -220,9 +223,9 @@ static int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expect
     sk->hash32 = k <= 16;
     sk->hash_max = sk->hash32 ? 0xFFFFFFFFull : ~0ull;
     sk->expected_bytes = expected_bytes;
-    // table: >= 2^22 slots, >= 1024 slots per sketch entry when a multiplicity filter makes
-    // early tightening impossible (coverage up to ~256x stays exact in one pass), else 256
-    uint64_t want = (uint64_t)s * (sk->m > 1 ? 1024 : 256);
+    // table: >= 2^22 slots, >= 256 slots per sketch entry (worst-case admissions of the
+    // occurrence bound at load 1; real inputs repeat their k-mers and stay far below)
+    uint64_t want = (uint64_t)s * 256;
     if (want < (1ull << 22)) want = 1ull << 22;
     if (expected_bytes && expected_bytes * 4 < want && expected_bytes * 4 >= (1ull << 16)) want = expected_bytes * 4;
     if (expected_bytes && expected_bytes * 4 < (1ull << 16)) want = 1ull << 16;
@@ -483,15 +486,27 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
 }
 
 static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
-{
-    std::vector<uint32_t> idx(keys.size());
-    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-    std::vector<uint64_t> k2(keys.size());
-    std::vector<uint32_t> c2(keys.size());
-    for (size_t i = 0; i < idx.size(); ++i) { k2[i] = keys[idx[i]]; c2[i] = cnts[idx[i]]; }
-    keys.swap(k2);
-    cnts.swap(c2);
+{ // LSD radix sort on the 64-bit keys (8 passes of 8 bits, passes with a constant byte skipped)
+    const size_t n = keys.size();
+    if (n < 2) return;
+    std::vector<uint64_t> k2(n);
+    std::vector<uint32_t> c2(n);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int sh = 8 * pass;
+        size_t hist[257] = {0};
+        for (size_t i = 0; i < n; ++i) ++hist[((keys[i] >> sh) & 0xFF) + 1];
+        bool trivial = false;
+        for (int b = 1; b <= 256; ++b) if (hist[b] == n) trivial = true;
+        if (trivial) continue;
+        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+        for (size_t i = 0; i < n; ++i) {
+            const size_t d = hist[(keys[i] >> sh) & 0xFF]++;
+            k2[d] = keys[i];
+            c2[d] = cnts[i];
+        }
+        keys.swap(k2);
+        cnts.swap(c2);
+    }
 }
 
 extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
