@@ -10,8 +10,14 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <zlib.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mhx_device.h"
@@ -756,6 +762,189 @@ static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t
     return fail(MHX_E_CAPACITY, "could not size the device table for this input");
 }
 
+// ---- streaming FASTQ ingest ---------------------------------------------------------------
+// Reads mode on real inputs is inflate-bound (zlib, ~0.1-0.3 GB/s per stream), so every input
+// file gets its own inflate thread; each thread cuts its stream into <= 32 MiB chunks at record
+// boundaries (a multiple of four lines since the start of the file) and hands them to the
+// caller's thread, which copies them to the device and pushes them through the FASTQ kernel
+// while the other files keep inflating.  Host memory stays bounded (a few chunks per file).
+namespace {
+constexpr size_t kIngestChunk = 32u << 20;
+
+struct IngestChunk {
+    std::vector<uint8_t> data;
+    int file = 0;
+    bool first_of_file = false;
+};
+
+class ChunkQueue {
+  public:
+    void put(IngestChunk &&c)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        room_.wait(lk, [&] { return q_.size() < 4 || abort_; });
+        if (abort_) return;
+        q_.push_back(std::move(c));
+        ready_.notify_one();
+    }
+    bool get(IngestChunk &out) // false when every producer is done and the queue is empty
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        ready_.wait(lk, [&] { return !q_.empty() || live_ == 0; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        room_.notify_one();
+        return true;
+    }
+    void producer_started() { std::lock_guard<std::mutex> lk(m_); ++live_; }
+    void producer_done() { std::lock_guard<std::mutex> lk(m_); --live_; ready_.notify_all(); }
+    void abort() { std::lock_guard<std::mutex> lk(m_); abort_ = true; room_.notify_all(); }
+    bool aborted() { std::lock_guard<std::mutex> lk(m_); return abort_; }
+
+  private:
+    std::mutex m_;
+    std::condition_variable ready_, room_;
+    std::deque<IngestChunk> q_;
+    int live_ = 0;
+    bool abort_ = false;
+};
+
+struct FileIngestState {
+    std::string error;
+    uint64_t lines = 0, bytes = 0;
+    bool not_fastq4 = false;
+};
+
+void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *st)
+{
+    gzFile g = gzopen(path, "rb");
+    if (!g) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
+    gzbuffer(g, 1 << 20);
+    std::vector<uint8_t> carry;
+    bool first = true;
+    uint64_t lines_before = 0; // newlines in everything already emitted
+    for (;;) {
+        IngestChunk c;
+        c.file = file;
+        c.first_of_file = first;
+        c.data.resize(kIngestChunk);
+        size_t n = carry.size();
+        if (n) memcpy(c.data.data(), carry.data(), n);
+        carry.clear();
+        bool eof = false;
+        while (n < kIngestChunk) {
+            const int got = gzread(g, c.data.data() + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
+            if (got < 0) { st->error = std::string("ERROR: reading ") + path + " failed"; gzclose(g); q->producer_done(); return; }
+            if (got == 0) { eof = true; break; }
+            n += (size_t)got;
+        }
+        if (first && n && c.data[0] != '@') { st->not_fastq4 = true; gzclose(g); q->producer_done(); return; }
+        // cut after the last newline that completes a record (line count multiple of 4)
+        size_t cut = 0;
+        uint64_t lines = lines_before, lines_at_cut = lines_before;
+        for (size_t off = 0; off < n;) {
+            const uint8_t *p = (const uint8_t *)memchr(c.data.data() + off, '\n', n - off);
+            if (!p) break;
+            ++lines;
+            off = (size_t)(p - c.data.data()) + 1;
+            if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; }
+        }
+        if (eof) {
+            // the tail must be whole records; a last record may lack its final newline
+            if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
+            cut = n;
+            lines_at_cut = lines + (n && c.data[n - 1] != '\n' ? 1 : 0);
+        } else if (cut == 0) {
+            st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
+        }
+        if (st->not_fastq4) { gzclose(g); q->producer_done(); return; }
+        if (cut < n) carry.assign(c.data.begin() + cut, c.data.begin() + n);
+        c.data.resize(cut);
+        st->bytes += cut;
+        st->lines = lines_at_cut;
+        lines_before = lines_at_cut;
+        first = false;
+        if (cut) q->put(std::move(c));
+        if (eof || q->aborted()) break;
+    }
+    gzclose(g);
+    q->producer_done();
+}
+
+uint64_t guess_inflated_bytes(const char *path)
+{
+    struct stat sb;
+    if (stat(path, &sb) != 0) return 0;
+    FILE *f = fopen(path, "rb");
+    uint8_t magic[2] = {0, 0};
+    if (f) { if (fread(magic, 1, 2, f) != 2) magic[0] = 0; fclose(f); }
+    const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
+    return (uint64_t)sb.st_size * (gz ? 8 : 1);
+}
+} // namespace
+
+// returns MHX_OK with *handled = true when the streaming path produced the sketch;
+// *handled = false means "not strict FASTQ / could not size": use the whole-file path.
+static int stream_fastq_reference(const char *const *paths, int n_paths, int k, uint32_t s, uint32_t m, std::vector<uint64_t> &hashes,
+                                  std::vector<uint32_t> &counts, uint64_t *kmers, uint64_t *records, std::string *fname,
+                                  std::string *fcomment, bool *handled)
+{
+    *handled = false;
+    uint64_t expected = 0;
+    for (int i = 0; i < n_paths; ++i) expected += guess_inflated_bytes(paths[i]);
+    mhx_sketcher *sk = nullptr;
+    int rc = mhx_sketcher_create(k, s, m, expected, &sk);
+    if (rc) return rc;
+    uint8_t *d_slot = nullptr;
+    if (hipMalloc((void **)&d_slot, kIngestChunk + 64) != hipSuccess) { mhx_sketcher_destroy(sk); return fail(MHX_E_HIP, "hipMalloc failed for the ingest slot"); }
+    ChunkQueue q;
+    std::vector<FileIngestState> st(n_paths);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n_paths; ++i) q.producer_started();
+    for (int i = 0; i < n_paths; ++i) threads.emplace_back(inflate_fastq, paths[i], i, &q, &st[i]);
+    IngestChunk c;
+    bool have_header = false;
+    while (q.get(c)) {
+        if (rc) continue; // drain
+        if (c.first_of_file && (!have_header || c.file == 0)) {
+            first_header(c.data.data(), c.data.size(), *fname, *fcomment);
+            have_header = true;
+        }
+        if (hipMemcpyAsync(d_slot, c.data.data(), c.data.size(), hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
+        rc = mhx_sketcher_push_device(sk, d_slot, c.data.size(), MHX_FMT_FASTQ4);
+        if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
+        if (rc) q.abort();
+    }
+    for (auto &t : threads) t.join();
+    bool fallback = false;
+    uint64_t total_lines = 0;
+    for (auto &f : st) {
+        if (!f.error.empty() && !rc) rc = fail(MHX_E_IO, "%s", f.error.c_str());
+        if (f.not_fastq4) fallback = true;
+        total_lines += f.lines;
+    }
+    uint32_t n = 0;
+    if (!rc && !fallback) {
+        hashes.resize(s);
+        counts.resize(s);
+        rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
+        if (rc == MHX_E_FORMAT || rc == MHX_E_CAPACITY) { fallback = true; rc = MHX_OK; clear_error(); }
+    }
+    if (!rc && !fallback) {
+        uint64_t stt[8];
+        rc = mhx_sketcher_stats(sk, stt);
+        *kmers = stt[0];
+        *records = total_lines / 4;
+        hashes.resize(n);
+        counts.resize(n);
+        *handled = true;
+    }
+    hipFree(d_slot);
+    mhx_sketcher_destroy(sk);
+    return rc;
+}
+
 extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
                                 const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
                                 double *est_genome_size)
@@ -776,23 +965,30 @@ extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, ui
         return fail(MHX_E_NO_RECORDS, "ERROR: Did not find fasta records in \"%s\".", p);
     };
     if (reads) {
-        std::vector<Loaded *> in;
-        for (int i = 0; i < n_paths; ++i) {
-            rc = read_all_maybe_gz(paths[i], loaded[i].raw);
-            if (rc) return rc;
-            loaded[i].fastq4 = looks_like_fastq4(loaded[i].raw.data(), loaded[i].raw.size());
-            in.push_back(&loaded[i]);
-        }
         RefSketch ref;
-        uint64_t kmers = 0;
-        rc = sketch_reference(in, k, s, min_mult ? min_mult : 1, true, ref.hashes, ref.counts, &kmers);
-        if (rc) return rc;
+        uint64_t kmers = 0, count = 0;
+        std::string fname, fcomment;
+        bool streamed = false;
+        if (!getenv("MHX_NO_STREAMING")) {
+            rc = stream_fastq_reference(paths, n_paths, k, s, min_mult ? min_mult : 1, ref.hashes, ref.counts, &kmers, &count, &fname, &fcomment, &streamed);
+            if (rc) return rc;
+        }
+        std::vector<Loaded *> in;
+        if (!streamed) {
+            for (int i = 0; i < n_paths; ++i) {
+                rc = read_all_maybe_gz(paths[i], loaded[i].raw);
+                if (rc) return rc;
+                loaded[i].fastq4 = looks_like_fastq4(loaded[i].raw.data(), loaded[i].raw.size());
+                in.push_back(&loaded[i]);
+            }
+            rc = sketch_reference(in, k, s, min_mult ? min_mult : 1, true, ref.hashes, ref.counts, &kmers);
+            if (rc) return rc;
+        }
         // name / comment / count: first counted record; count = records seen by the parser,
         // or lines / 4 when the stream went to the device parser untouched
-        std::string fname, fcomment;
-        uint64_t count = 0;
-        bool any = false;
+        bool any = streamed;
         for (auto &l : loaded) {
+            if (streamed) break;
             if (l.rec.records_seen || !l.rec.seq.empty()) {
                 if (!any && l.rec.records) { fname = l.rec.first_name; fcomment = l.rec.first_comment; any = true; }
                 count += l.rec.records;

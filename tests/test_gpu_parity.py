@@ -310,3 +310,28 @@ def test_dist_more_than_32_refs_and_k16_32bit_hashes():
     qrys = [np.unique(np.concatenate([refs[i][:400], _sketch_like(rng, 400, hi=2 ** 32)])) for i in range(6)]
     _check_all_pairs(qrys, refs, 16, 800)
     _check_all_pairs(qrys, refs[:24], 16, 800)          # fast path on 32-bit hash values
+
+
+def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
+    """Reads mode streams each file through its own inflate thread in 32 MiB record-aligned
+    chunks; two files, several chunks each, the second one without a final newline."""
+    import gzip
+
+    genome = synth.make_genome(400_000, seed=8)
+    a = synth.make_fastq(genome, 230_000, 150, seed=9, device="cpu").numpy().tobytes()       # 72 MB -> 3 chunks
+    b = synth.make_fastq(genome, 120_000, 150, seed=10, device="cpu", first_index=230_000).numpy().tobytes()[:-1]
+    pa, pb = tmp_path / "r1.fq.gz", tmp_path / "r2.fq"
+    with gzip.open(pa, "wb", compresslevel=1) as fh:
+        fh.write(a)
+    pb.write_bytes(b)
+    out = tmp_path / "s.msh"
+    stderr, est = engine.sketch_files([pa, pb], 21, 5000, out, reads=True, min_mult=2)
+    ref = mo.Sketcher(21, 5000, 2)
+    ref.add_fastx(a)
+    ref.add_fastx(b)
+    want, _ = ref.finish()
+    got = mo.read_msh(out)
+    assert np.array_equal(got.references[0].hashes, want)
+    assert got.references[0].comment == "[350000 seqs] r00000000  [...]"
+    assert got.references[0].length == int(ref.set_size)
+    assert "Estimated genome size: %g\n" % ref.set_size in stderr
