@@ -2,9 +2,9 @@
 backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests), each rank sketches its own
 record-aligned shard, then ONE exchange step merges the partial results:
 
-  1. all-reduce(MIN) of the ranks' admission thresholds  -> common limit T_min
+  1. all-gather of the ranks' 8-byte admission thresholds  -> common limit T_min = their minimum
   2. every rank exports all (hash, count) it saw with hash <= T_min (no multiplicity filter,
-     so counts stay summable), all-gather of the sizes, all-gather of the padded slabs
+     so counts stay summable) and all-gathers ONE fixed-size slab [n, hashes.., counts..]
   3. every rank merges: sum counts per hash, keep count >= m, first s ascending.
 
 Exact for any m: each rank's threshold never drops below the global s-th qualifying hash
@@ -13,7 +13,7 @@ counts.  The payload is a few thousand 12-byte entries per rank: latency-bound, 
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, List, Tuple
 
 import numpy as np
 import torch
@@ -26,39 +26,45 @@ def _to_i64(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(a.astype(np.uint64).view(np.int64).copy())
 
 
+def _gather(t: torch.Tensor) -> List[torch.Tensor]:
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
 def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.ndarray, np.ndarray]], s: int, min_mult: int,
                        merge: Callable[[np.ndarray, np.ndarray, int, int], Tuple[np.ndarray, np.ndarray]],
                        device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
     """The exchange step. `export(limit)` -> (hashes, counts) of this rank; `merge` = engine.merge_partials.
-    Works on any initialised process group; tensors live on `device` (cuda for nccl, cpu for gloo)."""
+    Works on any initialised process group; tensors live on `device` (cuda for nccl, cpu for gloo).
+    Two collectives: an all-gather of the 8-byte thresholds, and an all-gather of one fixed-size slab
+    per rank ([n, hashes.., counts..], 4*s + 4096 entries; a second, exact-size round only if a rank
+    holds more)."""
     world = dist.get_world_size()
-    # 1. common limit: min over ranks of a u64, done as two non-negative int64 halves
-    hi_lo = torch.tensor([local_threshold >> 32], dtype=torch.int64, device=device)
-    dist.all_reduce(hi_lo, op=dist.ReduceOp.MIN)
-    hi = int(hi_lo.item())
-    lo_t = torch.tensor([(local_threshold & 0xFFFFFFFF) if (local_threshold >> 32) == hi else 0xFFFFFFFF],
-                        dtype=torch.int64, device=device)
-    dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
-    t_min = (hi << 32) | int(lo_t.item())
+    # 1. common limit = min over ranks (u64 travels as int64 bits)
+    mine = torch.tensor([np.uint64(local_threshold).astype(np.uint64).view(np.int64)], dtype=torch.int64, device=device)
+    t_min = min(int(np.int64(x.item()).view(np.uint64)) for x in _gather(mine))
     # 2. slabs
     hashes, counts = export(t_min)
-    n_local = torch.tensor([len(hashes)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(x.item()) for x in sizes]
-    pad = max(max(sizes), 1)
-    slab = torch.zeros(2 * pad, dtype=torch.int64, device=device)
-    if len(hashes):
-        slab[:len(hashes)] = _to_i64(hashes).to(device)
-        slab[pad:pad + len(counts)] = torch.from_numpy(counts.astype(np.int64)).to(device)
-    slabs = [torch.empty_like(slab) for _ in range(world)]
-    dist.all_gather(slabs, slab)
+    cap = 4 * s + 4096
+    n = len(hashes)
+
+    def slab(capacity: int) -> torch.Tensor:
+        buf = np.zeros(1 + 2 * capacity, dtype=np.int64)
+        buf[0] = n
+        m = min(n, capacity)
+        buf[1:1 + m] = hashes[:m].view(np.int64)
+        buf[1 + capacity:1 + capacity + m] = counts[:m]
+        return torch.from_numpy(buf).to(device)
+
+    got = [x.cpu().numpy() for x in _gather(slab(cap))]
+    sizes = [int(g[0]) for g in got]
+    if max(sizes) > cap:   # rare: a rank saw more distinct hashes below the limit than the fixed slab holds
+        cap = max(sizes)
+        got = [x.cpu().numpy() for x in _gather(slab(cap))]
     # 3. merge
-    all_h, all_c = [], []
-    for r in range(world):
-        v = slabs[r].cpu().numpy()
-        all_h.append(v[:sizes[r]].view(np.uint64))
-        all_c.append(v[pad:pad + sizes[r]].astype(np.uint32))
+    all_h = [g[1:1 + sizes[r]].view(np.uint64) for r, g in enumerate(got)]
+    all_c = [g[1 + cap:1 + cap + sizes[r]].astype(np.uint32) for r, g in enumerate(got)]
     return merge(np.concatenate(all_h), np.concatenate(all_c), s, min_mult)
 
 

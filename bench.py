@@ -57,7 +57,8 @@ def main() -> None:
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MHX_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -79,7 +80,7 @@ def main() -> None:
     def step():
         sk.reset()
         sk.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
-        if world == 1:
+        if not use_dist:
             return sk.finish()
         t = sk.threshold()
         return multigpu.exchange_and_merge(t, sk.export, args.s, args.m, engine.merge_partials, comm_dev)
@@ -87,7 +88,7 @@ def main() -> None:
     def barrier():
         torch.cuda.synchronize()
         sk.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -98,7 +99,7 @@ def main() -> None:
         result = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -169,10 +170,12 @@ def main() -> None:
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "parity_on_sample": parity, "sketch_len": int(len(result[0])),
         }
-        print(json.dumps(line), flush=True)
     sk.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)   # the one JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
