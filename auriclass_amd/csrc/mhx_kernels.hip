@@ -100,7 +100,7 @@ __device__ uint32_t lookback_wave(uint64_t *state, uint32_t tile, uint32_t first
             pos -= 64;
             continue;
         }
-        if (++spins > (1u << 24)) { // ~seconds; never reached in a healthy launch
+        if (++spins > (1u << 20)) { // ~a second; never reached in a healthy launch
             if (lane == 0) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagSpinTimeout);
             break;
         }
