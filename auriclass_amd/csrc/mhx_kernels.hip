@@ -135,7 +135,10 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t value, uint32_t *wa
 }
 
 // ---------------------------------------------------------------------------------------
-template <int K, int FMT> __global__ __launch_bounds__(kBlock) void sketch_tile_kernel(const HashArgs a)
+#ifndef MHX_MIN_WAVES
+#define MHX_MIN_WAVES 1
+#endif
+template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) void sketch_tile_kernel(const HashArgs a)
 {
     __shared__ TileSmem sm;
     constexpr bool FASTQ = (FMT == 1);
