@@ -200,22 +200,32 @@ def test_multiline_fastq_falls_back_to_record_parser(tmp_path):
     assert np.array_equal(got, want)
 
 
-def test_C2_synthetic_assembly_fasta_k21_s1000(tmp_path):
-    genome = synth.make_genome(1_200_000, seed=42)
+@pytest.mark.parametrize("k,s", [(21, 1000), (27, 50000)])
+def test_C2_synthetic_assembly_vs_24_refs(tmp_path, k, s):
+    """BASELINE.json config 2 with the stand-ins of SURVEY.md 8(d): a 12 Mb genome in 20 contigs
+    (70-column FASTA), 24 references mutated at rates 0.0005 .. 0.05, sketched by the oracle; the
+    engine sketches the query and computes the 24 distance rows.  (k=21, s=1000) and AuriClass's
+    defaults (k=27, s=50000)."""
+    genome = synth.make_genome(12_000_000, seed=42)
     fa = tmp_path / "asm.fasta"
     fa.write_bytes(synth.genome_fasta(genome, 20))
-    engine.sketch_files([fa], 21, 1000, tmp_path / "a.msh")
-    osk, _ = mo.sketch_files([fa], 21, 1000)
+    engine.sketch_files([fa], k, s, tmp_path / "a.msh")
+    osk, _ = mo.sketch_files([fa], k, s)
     assert (tmp_path / "a.msh").read_bytes() == mo.msh_bytes(osk)
-    # refs: mutated copies, sketched by the oracle, distances by the engine
+    assert osk.references[0].length == 12_000_000 and len(osk.references[0].hashes) == s
+    rates = np.geomspace(0.0005, 0.05, 24)
     refs = []
-    for i, rate in enumerate([0.0005, 0.005, 0.05]):
-        rp = tmp_path / ("ref%d.fasta" % i)
-        rp.write_bytes(synth.genome_fasta(synth.mutate(genome, rate, 100 + i), 20, name="r%d" % i))
-        refs.append(rp)
-    rsk, _ = mo.sketch_files(refs, 21, 1000)
+    for i, rate in enumerate(rates):
+        g = synth.mutate(genome, float(rate), 100 + i)
+        rs = mo.Sketcher(k, s, 1)
+        rs.add_seq(g.tobytes())
+        refs.append(mo.Reference("ref_%02d.fasta" % i, "synthetic clade ref %d" % i, len(g), rs.finish()[0]))
+    rsk = mo.SketchFile(kmer_size=k, sketch_size=s, references=refs)
     mo.write_msh(tmp_path / "refs.msh", rsk)
-    assert engine.dist_files(tmp_path / "refs.msh", tmp_path / "a.msh") == mo.dist_text(rsk, osk)
+    text = engine.dist_files(tmp_path / "refs.msh", tmp_path / "a.msh")
+    assert text == mo.dist_text(rsk, osk)
+    d = [float(l.split("\t")[2]) for l in text.splitlines()]
+    assert len(d) == 24 and d[0] < d[-1] and d[0] < 0.002        # closest ref first, distances grow with the mutation rate
 
 
 # ---- batched distance -------------------------------------------------------------------------
