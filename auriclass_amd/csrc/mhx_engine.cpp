@@ -813,10 +813,11 @@ class ChunkQueue {
 struct FileIngestState {
     std::string error;
     uint64_t lines = 0, bytes = 0;
+    uint64_t counted = 0; // records whose sequence line holds >= k bases (mash's `count`)
     bool not_fastq4 = false;
 };
 
-void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *st)
+void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestState *st)
 {
     gzFile g = gzopen(path, "rb");
     if (!g) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
@@ -841,20 +842,25 @@ void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *s
         }
         if (first && n && c.data[0] != '@') { st->not_fastq4 = true; gzclose(g); q->producer_done(); return; }
         // cut after the last newline that completes a record (line count multiple of 4)
-        size_t cut = 0;
-        uint64_t lines = lines_before, lines_at_cut = lines_before;
+        size_t cut = 0, tail_from = 0;
+        uint64_t lines = lines_before, lines_at_cut = lines_before, counted = 0, counted_at_cut = 0;
         for (size_t off = 0; off < n;) {
             const uint8_t *p = (const uint8_t *)memchr(c.data.data() + off, '\n', n - off);
-            if (!p) break;
+            if (!p) { tail_from = off; break; }
+            const size_t len = (size_t)(p - c.data.data()) - off;
+            if ((lines & 3) == 1 && len >= (size_t)k) ++counted; // line index 1 of a record = its bases
             ++lines;
             off = (size_t)(p - c.data.data()) + 1;
-            if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; }
+            tail_from = off;
+            if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; counted_at_cut = counted; }
         }
         if (eof) {
             // the tail must be whole records; a last record may lack its final newline
             if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
             cut = n;
             lines_at_cut = lines + (n && c.data[n - 1] != '\n' ? 1 : 0);
+            counted_at_cut = counted;
+            (void)tail_from;
         } else if (cut == 0) {
             st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
         }
@@ -863,6 +869,7 @@ void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *s
         c.data.resize(cut);
         st->bytes += cut;
         st->lines = lines_at_cut;
+        st->counted += counted_at_cut;
         lines_before = lines_at_cut;
         first = false;
         if (cut) q->put(std::move(c));
@@ -902,7 +909,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     std::vector<FileIngestState> st(n_paths);
     std::vector<std::thread> threads;
     for (int i = 0; i < n_paths; ++i) q.producer_started();
-    for (int i = 0; i < n_paths; ++i) threads.emplace_back(inflate_fastq, paths[i], i, &q, &st[i]);
+    for (int i = 0; i < n_paths; ++i) threads.emplace_back(inflate_fastq, paths[i], i, k, &q, &st[i]);
     IngestChunk c;
     bool have_header = false;
     while (q.get(c)) {
@@ -918,11 +925,11 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     }
     for (auto &t : threads) t.join();
     bool fallback = false;
-    uint64_t total_lines = 0;
+    uint64_t total_counted = 0;
     for (auto &f : st) {
         if (!f.error.empty() && !rc) rc = fail(MHX_E_IO, "%s", f.error.c_str());
         if (f.not_fastq4) fallback = true;
-        total_lines += f.lines;
+        total_counted += f.counted;
     }
     uint32_t n = 0;
     if (!rc && !fallback) {
@@ -935,7 +942,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         uint64_t stt[8];
         rc = mhx_sketcher_stats(sk, stt);
         *kmers = stt[0];
-        *records = total_lines / 4;
+        *records = total_counted;
         hashes.resize(n);
         counts.resize(n);
         *handled = true;

@@ -30,6 +30,44 @@ from auriclass_amd import engine, multigpu, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def cpu_baseline_run(sample: np.ndarray, rb: int, k: int, s: int, m: int, cores: int):
+    """CPU baseline on the GPU box's host cores: the C oracle on `cores` record shards, one process
+    each (the reference's own advice is one process per input, docs/running_analysis.md:47-59), the
+    partial sketches merged.  Bottom-s partials only merge exactly for m = 1, so m > 1 runs as one
+    process.  Returns (sketch of the whole sample, wall seconds incl. process start, cores used)."""
+    import subprocess
+    import tempfile
+
+    from oracle import mash_oracle as mo
+
+    n = sample.size // rb
+    mo.lib()  # compile the oracle before anything is timed
+    if m > 1 or cores <= 1 or n < cores:
+        ref = mo.Sketcher(k, s, m)
+        t0 = time.perf_counter()
+        ref.add_fastx(sample.tobytes())
+        want, _ = ref.finish()
+        return want, time.perf_counter() - t0, 1
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        path = os.path.join(td, "sample.fq")
+        sample.tofile(path)
+        env = dict(os.environ, PYTHONPATH=str(ROOT))
+        t0 = time.perf_counter()
+        procs = []
+        for r in range(cores):
+            lo, hi = multigpu.shard_bounds(n, cores, r)
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.shard_worker", path, str(lo * rb), str(hi * rb),
+                                           str(k), str(s), os.path.join(td, f"p{r}.npy")], env=env, cwd=str(ROOT)))
+        for p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("cpu baseline worker failed")
+        parts = [np.load(os.path.join(td, f"p{r}.npy")) for r in range(cores)]
+        want = np.unique(np.concatenate(parts))[:s]
+        wall = time.perf_counter() - t0
+    return want, wall, cores
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,7 +79,8 @@ def main() -> None:
     ap.add_argument("--s", type=int, default=1000)
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--genome", type=int, default=12_000_000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
+    ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -137,21 +176,15 @@ def main() -> None:
 
         # ---- CPU baseline + parity on a bounded sample of the same workload -------------------
         if not args.no_cpu_baseline:
-            from oracle import mash_oracle as mo
-
             n_s = min(args.cpu_sample_reads, args.reads)
             rb = synth.record_bytes(args.read_len)
             sample = fq[: n_s * rb].cpu().numpy()
-            data = sample.tobytes()
-            ref = mo.Sketcher(args.k, args.s, args.m)
-            c0 = time.perf_counter()
-            ref.add_fastx(data)
-            want, _ = ref.finish()
-            cpu_s = time.perf_counter() - c0
-            cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": 1,
+            want, cpu_s, cores = cpu_baseline_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
+            cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": cores,
                             "kind": "port",
-                            "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input, "
-                                      f"parse + sketch by the C oracle (oracle/mashcore.c), {cpu_s:.1f} s"}
+                            "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input in {cores} record "
+                                      f"shards, one process each: parse + sketch by the C oracle (oracle/mashcore.c), partial "
+                                      f"sketches merged; wall {cpu_s:.1f} s"}
             sk2 = engine.Sketcher(args.k, args.s, args.m, expected_bytes=sample.size)
             sk2.push_device(fq.data_ptr(), n_s * rb, engine.FMT_FASTQ4)
             got, _ = sk2.finish()

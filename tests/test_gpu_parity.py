@@ -329,7 +329,9 @@ def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
 
     genome = synth.make_genome(400_000, seed=8)
     a = synth.make_fastq(genome, 230_000, 150, seed=9, device="cpu").numpy().tobytes()       # 72 MB -> 3 chunks
-    b = synth.make_fastq(genome, 120_000, 150, seed=10, device="cpu", first_index=230_000).numpy().tobytes()[:-1]
+    b = synth.make_fastq(genome, 120_000, 150, seed=10, device="cpu", first_index=230_000).numpy().tobytes()
+    b += b"".join(b"@short%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(7))      # shorter than k: not counted by mash
+    b = b[:-1]
     pa, pb = tmp_path / "r1.fq.gz", tmp_path / "r2.fq"
     with gzip.open(pa, "wb", compresslevel=1) as fh:
         fh.write(a)
@@ -342,6 +344,7 @@ def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
     want, _ = ref.finish()
     got = mo.read_msh(out)
     assert np.array_equal(got.references[0].hashes, want)
-    assert got.references[0].comment == "[350000 seqs] r00000000  [...]"
+    assert ref.records == 350_000
+    assert got.references[0].comment == ref.comment() == "[350000 seqs] r00000000  [...]"
     assert got.references[0].length == int(ref.set_size)
     assert "Estimated genome size: %g\n" % ref.set_size in stderr
