@@ -348,3 +348,34 @@ def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
     assert got.references[0].comment == ref.comment() == "[350000 seqs] r00000000  [...]"
     assert got.references[0].length == int(ref.set_size)
     assert "Estimated genome size: %g\n" % ref.set_size in stderr
+
+
+@pytest.mark.parametrize("k,s", [(16, 400), (11, 200), (32, 300), (21, 1000)])
+def test_file_level_multi_record_fasta_with_iupac_and_lowercase(tmp_path, k, s):
+    """Unpinned-by-reference corners at the file boundary, engine vs oracle byte for byte: multi-record
+    FASTA ('[N seqs] ... [...]' comment), records shorter than k, N / IUPAC / lower-case bases, CRLF
+    line ends, 32-bit hash lists (k <= 16) and k = 32."""
+    rng = np.random.default_rng(k * 31 + s)
+    recs = []
+    for i in range(40):
+        L = int(rng.integers(5, 900))
+        seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+        for _ in range(int(rng.integers(0, 3))):
+            seq[int(rng.integers(0, L))] = rng.choice(np.frombuffer(b"NRYKMSW", np.uint8))
+        seq = bytes(seq)
+        if i % 3 == 0:
+            seq = seq.lower()
+        wrapped = b"\n".join(seq[j:j + 60] for j in range(0, L, 60))
+        recs.append(b">rec%d some description %d\n" % (i, i) + wrapped + b"\n")
+    fa = tmp_path / "multi.fa"
+    fa.write_bytes(b"".join(recs))
+    crlf = tmp_path / "crlf.fa"
+    crlf.write_bytes(b"".join(recs[:5]).replace(b"\n", b"\r\n"))
+    engine.sketch_files([fa, crlf], k, s, tmp_path / "e.msh")
+    osk, _ = mo.sketch_files([fa, crlf], k, s)
+    assert (tmp_path / "e.msh").read_bytes() == mo.msh_bytes(osk)
+    assert osk.references[0].comment.startswith("[") and " seqs] rec" in osk.references[0].comment
+    if k <= 16:
+        assert max(int(r.hashes.max()) for r in osk.references) < 2 ** 32
+    # the engine reads its own container back for distances
+    assert engine.dist_files(tmp_path / "e.msh", tmp_path / "e.msh") == mo.dist_text(osk, osk)
