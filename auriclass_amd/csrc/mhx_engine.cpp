@@ -632,10 +632,11 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         A(&dq, (size_t)nq * stride * 8); A(&dr, (size_t)nr * stride * 8); A(&dql, (size_t)nq * 4); A(&drl, (size_t)nr * 4);
         A(&dc, pairs * 4); A(&dd, pairs * 4);
         if (e != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "hipMalloc failed in dist_batch: %s", hipGetErrorString(e)); }
-        hipMemcpyAsync(dq, q, (size_t)nq * stride * 8, hipMemcpyHostToDevice, g.stream);
-        hipMemcpyAsync(dr, r, (size_t)nr * stride * 8, hipMemcpyHostToDevice, g.stream);
-        hipMemcpyAsync(dql, q_len, (size_t)nq * 4, hipMemcpyHostToDevice, g.stream);
-        hipMemcpyAsync(drl, r_len, (size_t)nr * 4, hipMemcpyHostToDevice, g.stream);
+        hipError_t ce = hipMemcpyAsync(dq, q, (size_t)nq * stride * 8, hipMemcpyHostToDevice, g.stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(dr, r, (size_t)nr * stride * 8, hipMemcpyHostToDevice, g.stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(dql, q_len, (size_t)nq * 4, hipMemcpyHostToDevice, g.stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(drl, r_len, (size_t)nr * 4, hipMemcpyHostToDevice, g.stream);
+        if (ce != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "H2D copy failed in dist_batch: %s", hipGetErrorString(ce)); }
         a.q = (const uint64_t *)dq; a.q_len = (const uint32_t *)dql; a.r = (const uint64_t *)dr; a.r_len = (const uint32_t *)drl;
         a.common = (uint32_t *)dc; a.denom = (uint32_t *)dd; a.dist = nullptr; // distances in host libm below
     }
@@ -666,11 +667,12 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
     }
     hipEventRecord(g.ev1, g.stream);
     if (le != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le)); }
+    hipError_t se = hipSuccess;
     if (!device_ptrs) {
-        hipMemcpyAsync(common, dc, pairs * 4, hipMemcpyDeviceToHost, g.stream);
-        hipMemcpyAsync(denom, dd, pairs * 4, hipMemcpyDeviceToHost, g.stream);
+        se = hipMemcpyAsync(common, dc, pairs * 4, hipMemcpyDeviceToHost, g.stream);
+        if (se == hipSuccess) se = hipMemcpyAsync(denom, dd, pairs * 4, hipMemcpyDeviceToHost, g.stream);
     }
-    hipError_t se = hipStreamSynchronize(g.stream);
+    if (se == hipSuccess) se = hipStreamSynchronize(g.stream);
     float ms = 0.f;
     hipEventElapsedTime(&ms, g.ev0, g.ev1);
     g.last_dist_ms = ms;
