@@ -173,3 +173,25 @@ def test_strand_decision_fallback_branch(emul, k):
     data = b"\n".join(reads) + b"\n"
     got, _ = run_emul(emul, data, k, fmt=0)
     assert np.array_equal(got, oracle_hashes(reads, k))
+
+
+def test_fastq4_crlf_and_plus_line_with_text(emul):
+    rng = np.random.default_rng(77)
+    reads = random_reads(rng, 500, 20, 200)
+    quals = np.frombuffer(b"!#+@ACGTIJ5<?", np.uint8)
+    rec = [b"@r%d\r\n" % i + r + b"\r\n+r%d repeated\r\n" % i + bytes(rng.choice(quals, size=len(r))) + b"\r\n"
+           for i, r in enumerate(reads)]
+    data = b"".join(rec)
+    got, stats = run_emul(emul, data, 21, fmt=1, lead=5)
+    assert int(stats[3]) == 0
+    assert np.array_equal(got, oracle_hashes(reads, 21))
+
+
+def test_fastq4_empty_reads_and_single_record(emul):
+    rec = b"@a\n\n+\n\n" + b"@b\nACGTACGTACGTACGTACGTACGTA\n+\nIIIIIIIIIIIIIIIIIIIIIIIII\n" + b"@c\n\n+\n\n"
+    got, stats = run_emul(emul, rec, 21, fmt=1)
+    assert int(stats[3]) == 0 and int(stats[2]) == 12
+    assert np.array_equal(got, oracle_hashes([b"ACGTACGTACGTACGTACGTACGTA"], 21))
+    one = b"@only\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40
+    got, stats = run_emul(emul, one, 21, fmt=1, lead=9)
+    assert np.array_equal(got, oracle_hashes([b"ACGT" * 10], 21))
