@@ -143,6 +143,9 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     __shared__ TileSmem sm;
     constexpr bool FASTQ = (FMT == 1);
     const int tid = threadIdx.x;
+#ifdef MHX_PRIO_PRE
+    __builtin_amdgcn_s_setprio(MHX_PRIO_PRE);
+#endif
 
     // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
     uint32_t tile;

@@ -9,7 +9,7 @@ using namespace mhx;
 
 struct CountIns { unsigned long long *sink; __device__ void operator()(uint64_t h) { atomicAdd(sink, (unsigned long long)h); } };
 
-template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, uint64_t T)
+template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, uint64_t T, uint32_t desync)
 {
     __shared__ TileSmem sm;
     const int tid = threadIdx.x;
@@ -23,6 +23,12 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
     __syncthreads();
     CountIns ins{out};
     uint64_t acc = 0;
+    if (desync) { // break the lockstep of the waves: each starts at its own time
+        const uint32_t wv = blockIdx.x * 4 + tid / 64;
+        const uint32_t wait = (wv * 2654435761u) % desync;
+        const uint64_t w0 = clock64();
+        while (clock64() - w0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     const uint64_t t0 = clock64();
     if (MODE == 0) {
         uint32_t w[8] = {b[tid], b[tid + 1], b[tid + 2], b[tid + 3], b[tid + 4], b[tid + 5] & 0xFF, 0, 0};
@@ -42,17 +48,17 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
     if ((tid & 63) == 0) out[2 + blockIdx.x * 4 + tid / 64] = t1 - t0;
 }
 
-template <int MODE> void run(const char *name, unsigned long long *d)
+template <int MODE> void run(const char *name, unsigned long long *d, uint32_t desync)
 {
     const int iters = 64;
     printf("%-28s", name);
     for (int bpc = 1; bpc <= 3; ++bpc) {
         const int blocks = 256 * bpc;
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0ull);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0ull, desync);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0ull);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0ull, desync);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h(2 + blocks * 4);
@@ -67,7 +73,8 @@ template <int MODE> void run(const char *name, unsigned long long *d)
 int main()
 {
     unsigned long long *d; hipMalloc(&d, (2 + 1024 * 4) * 8); hipMemset(d, 0, (2 + 1024 * 4) * 8);
-    run<0>("murmur3_h1<21> only", d);
-    run<1>("process_group<21> (8 windows)", d);
+    run<0>("murmur3_h1<21> only", d, 0);
+    run<1>("process_group<21> (8 windows)", d, 0);
+    run<1>("process_group, waves desynchronised", d, 50000);
     return 0;
 }
