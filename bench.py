@@ -161,11 +161,15 @@ def main() -> None:
         engine.set_profiling(False)
         kernel_ms = float(np.median(ms))
         achieved = nbytes / (kernel_ms / 1e3) / 1e9
+        # HBM bytes per step from the PMC passes (profiles/traffic.json), only quoted for the very
+        # workload they were collected on
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get("sketch_tile_kernel_hbm_bytes_per_step")
+                tj = json.loads(tf.read_text())
+                if tj.get("algorithmic_bytes_per_step") == nbytes and (args.k, args.s, args.m) == (21, 1000, 1):
+                    traffic = tj.get("sketch_tile_kernel_hbm_bytes_per_step")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
