@@ -147,6 +147,7 @@ struct mhx_sketcher {
     bool settled = false;          // threshold tight enough: remaining data goes in one launch
     uint64_t bytes_pushed = 0;
     uint64_t expected_bytes = 0;
+    uint64_t admit_scale = 1;      // multiplies the initial admission budget (retries after MHX_E_CAPACITY)
     double hash_ms = 0.0;
     uint64_t launches = 0;
     uint64_t last_T = 0;
@@ -198,7 +199,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
         // at most 256*s admissions over the whole expected input: stays exact up to ~256x
         // coverage (the s-th qualifying hash sits near s/D for D distinct solid k-mers, and the
         // input holds about coverage*D windows), and duplicates keep the table far emptier
-        const long double frac = (long double)(256.0L * sk->s) / (long double)sk->expected_bytes;
+        const long double frac = (long double)(256.0L * sk->s * sk->admit_scale) / (long double)sk->expected_bytes;
         if (frac < 1.0L) T = (uint64_t)(frac * (long double)sk->hash_max);
     }
     sk->t_init = T;
@@ -229,6 +230,7 @@ static int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expect
     sk->hash32 = k <= 16;
     sk->hash_max = sk->hash32 ? 0xFFFFFFFFull : ~0ull;
     sk->expected_bytes = expected_bytes;
+    sk->admit_scale = table_scale ? table_scale : 1;
     // table: >= 2^22 slots, >= 256 slots per sketch entry (worst-case admissions of the
     // occurrence bound at load 1; real inputs repeat their k-mers and stay far below)
     uint64_t want = (uint64_t)s * 256;

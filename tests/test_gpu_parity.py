@@ -379,3 +379,28 @@ def test_file_level_multi_record_fasta_with_iupac_and_lowercase(tmp_path, k, s):
         assert max(int(r.hashes.max()) for r in osk.references) < 2 ** 32
     # the engine reads its own container back for distances
     assert engine.dist_files(tmp_path / "e.msh", tmp_path / "e.msh") == mo.dist_text(osk, osk)
+
+
+def test_low_coverage_reads_with_multiplicity_filter_retry_path(tmp_path):
+    """Coverage 0.3 with m = 3: fewer qualifying k-mers lie below the initial admission bound than
+    the sketch needs, so the first attempt must be rejected (MHX_E_CAPACITY inside the library) and
+    the file-level call must come back with the exact sketch from a wider bound."""
+    genome = synth.make_genome(60_000_000, seed=77)
+    fq = synth.make_fastq(genome, 120_000, 150, seed=78, device="cpu").numpy()
+    p = tmp_path / "lowcov.fq"
+    fq.tofile(p)
+    # buffer level: the tight bound is detected, not silently accepted
+    sk = engine.Sketcher(21, 20_000, 3, expected_bytes=fq.size)
+    sk.push_host(fq, engine.FMT_FASTQ4)
+    with pytest.raises(engine.EngineError) as e:
+        sk.finish()
+    assert e.value.code == engine.MHX_E_CAPACITY
+    sk.close()
+    # file level: retried internally
+    engine.sketch_files([p], 21, 20_000, tmp_path / "l.msh", reads=True, min_mult=3)
+    ref = mo.Sketcher(21, 20_000, 3)
+    ref.add_fastx(fq.tobytes())
+    want, _ = ref.finish()
+    got = mo.read_msh(tmp_path / "l.msh").references[0].hashes
+    assert len(want) == 20_000
+    assert np.array_equal(got, want)
