@@ -145,6 +145,7 @@ struct mhx_sketcher {
     // host
     uint64_t next_chunk_bytes = 0; // geometric schedule of the tightening phase
     bool settled = false;          // threshold tight enough: remaining data goes in one launch
+    uint64_t settled_total = 0;    // input size that decision was made for
     uint64_t bytes_pushed = 0;
     uint64_t expected_bytes = 0;
     uint64_t admit_scale = 1;      // multiplies the initial admission budget (retries after MHX_E_CAPACITY)
@@ -211,6 +212,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
     sk->next_chunk_bytes = c0;
     sk->settled = false;
+    sk->settled_total = 0;
     sk->bytes_pushed = 0;
     sk->hash_ms = 0.0;
     sk->launches = 0;
@@ -303,6 +305,8 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     const uint64_t ntiles64 = (a.end + kTileBytes - 1) / kTileBytes;
     if (ntiles64 > 0x7FFFFFFFull) return fail(MHX_E_ARG, "span too large for one push (%llu bytes)", (unsigned long long)n);
     const uint32_t ntiles = (uint32_t)ntiles64;
+    // more input than the settling decision assumed: tighten again before admitting it wholesale
+    if (sk->settled && sk->bytes_pushed + n > 2 * sk->settled_total) sk->settled = false;
     if (fmt == MHX_FMT_FASTQ4) {
         if (sk->tile_state_cap < ntiles) {
             HIPCHK(hipStreamSynchronize(g.stream));
@@ -352,7 +356,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             const uint64_t total = sk->expected_bytes > sk->bytes_pushed ? sk->expected_bytes : (uint64_t)ntiles * kTileBytes;
             const uint64_t remaining = total > sk->bytes_pushed ? total - sk->bytes_pushed : (uint64_t)(ntiles - tile) * kTileBytes;
             const long double admit = (long double)remaining * ((long double)T / (long double)sk->hash_max);
-            if (admit <= (long double)(sk->nslots / 8)) sk->settled = true;
+            if (admit <= (long double)(sk->nslots / 8)) { sk->settled = true; sk->settled_total = total > sk->bytes_pushed ? total : sk->bytes_pushed; }
             else sk->next_chunk_bytes *= 4;
         }
     }

@@ -404,3 +404,23 @@ def test_low_coverage_reads_with_multiplicity_filter_retry_path(tmp_path):
     got = mo.read_msh(tmp_path / "l.msh").references[0].hashes
     assert len(want) == 20_000
     assert np.array_equal(got, want)
+
+
+def test_many_pushes_far_beyond_the_expected_size_stay_exact():
+    """expected_bytes is only a hint: 40 pushes totalling 50x the hint must neither overflow the
+    candidate table nor lose exactness (the engine re-tightens its threshold as the input grows)."""
+    genome = synth.make_genome(2_000_000, seed=90)
+    chunks = [synth.make_fastq(genome, 25_000, 150, seed=100 + i, device="cpu", first_index=i * 25_000).numpy() for i in range(40)]
+    for m in (1, 2):
+        sk = engine.Sketcher(21, 2000, m, expected_bytes=chunks[0].size // 2)
+        for c in chunks:
+            sk.push_host(c, engine.FMT_FASTQ4)
+        got, _ = sk.finish()
+        st = sk.stats()
+        sk.close()
+        ref = mo.Sketcher(21, 2000, m)
+        for c in chunks:
+            ref.add_fastx(c.tobytes())
+        want, _ = ref.finish()
+        assert np.array_equal(got, want)
+        assert st["flags"] == 0
