@@ -1,0 +1,43 @@
+"""C3 beyond the headline metric: the same 10 M x 150 bp reads with the host-to-device copy
+inside the timed region, and through the file-level call (plain file in /dev/shm; a 1 M-read .gz sample for
+the inflate-bound case)."""
+import gzip, os, sys, tempfile, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from auriclass_amd import engine, synth
+engine.init(0)
+g = synth.make_genome(12_000_000, 42)
+n = 10_000_000
+fq = synth.make_fastq(g, n, 150, 43, device="cuda")
+torch.cuda.synchronize()
+host = fq.cpu().numpy()
+bases = n * 150
+sk = engine.Sketcher(21, 1000, 1, expected_bytes=host.size)
+for name, fn in (("device-resident", lambda: sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)),
+                 ("H2D-inclusive (pageable numpy buffer)", lambda: sk.push_host(host, engine.FMT_FASTQ4))):
+    ts = []
+    for _ in range(4):
+        sk.reset(); t0 = time.perf_counter(); fn(); h, _ = sk.finish(); ts.append(time.perf_counter() - t0)
+    t = min(ts[1:])
+    print(f"{name:42s} {1e3*t:8.1f} ms  {bases/t/1e9:7.2f} Gbases/s")
+sk.close()
+d = tempfile.mkdtemp(dir="/dev/shm")
+p = os.path.join(d, "reads.fq"); host.tofile(p)
+for k, s, m in ((21, 1000, 1), (27, 50000, 3)):
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter(); engine.sketch_files([p], k, s, os.path.join(d, "o.msh"), reads=True, min_mult=m); ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    print(f"file-inclusive plain FASTQ k={k} s={s} m={m}      {1e3*t:8.1f} ms  {bases/t/1e9:7.2f} Gbases/s")
+rb = synth.record_bytes(150)
+pg = os.path.join(d, "r1.fq.gz")
+with gzip.open(pg, "wb", compresslevel=1) as fh:
+    fh.write(host[: 1_000_000 * rb].tobytes())
+pg2 = os.path.join(d, "r2.fq.gz")
+with gzip.open(pg2, "wb", compresslevel=1) as fh:
+    fh.write(host[1_000_000 * rb: 2_000_000 * rb].tobytes())
+for files in ([pg], [pg, pg2]):
+    t0 = time.perf_counter(); engine.sketch_files(files, 27, 50000, os.path.join(d, "o.msh"), reads=True, min_mult=3); t = time.perf_counter() - t0
+    nb = len(files) * 1_000_000 * 150
+    print(f"file-inclusive {len(files)} x 1 M-read .fq.gz (k=27 s=50000 m=3) {1e3*t:8.1f} ms  {nb/t/1e9:7.3f} Gbases/s")
+import shutil; shutil.rmtree(d)
