@@ -68,6 +68,35 @@ def cpu_baseline_run(sample: np.ndarray, rb: int, k: int, s: int, m: int, cores:
     return want, wall, cores
 
 
+def stock_mash_run(sample: np.ndarray, rb: int, k: int, s: int, m: int, cores: int):
+    """if a stock `mash` binary is installed on this host, time it on the same
+    sample, one process per record shard (`mash sketch -r` is single-threaded).  Returns None when there
+    is no such binary (the usual case: only this repository travels to the GPU box)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("mash")
+    if exe is None or "auriclass_amd" in os.path.realpath(exe):   # never time our own shim as "stock mash"
+        return None
+    n = sample.size // rb
+    cores = max(1, min(cores, n))
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        files = []
+        for r in range(cores):
+            lo, hi = multigpu.shard_bounds(n, cores, r)
+            f = os.path.join(td, f"shard{r}.fq")
+            sample[lo * rb:hi * rb].tofile(f)
+            files.append(f)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([exe, "sketch", "-r", "-m", str(m), "-k", str(k), "-s", str(s), "-o", f + ".out", f],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for f in files]
+        ok = all(p.wait() == 0 for p in procs)
+        wall = time.perf_counter() - t0
+    return (wall, cores) if ok else None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +218,13 @@ def main() -> None:
                             "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input in {cores} record "
                                       f"shards, one process each: parse + sketch by the C oracle (oracle/mashcore.c), partial "
                                       f"sketches merged; wall {cpu_s:.1f} s"}
+            stock = stock_mash_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
+            if stock is not None:   # a real mash on this host: that is the baseline to quote
+                cpu_baseline = {"value": round(n_s * args.read_len / stock[0] / 1e9, 5), "unit": "Gbases/s", "cores": stock[1],
+                                "kind": "reference",
+                                "sample": f"stock mash sketch -r -m {args.m} -k {args.k} -s {args.s} on the first {n_s} reads in "
+                                          f"{stock[1]} record shards, one process each; wall {stock[0]:.1f} s; C-oracle port on the "
+                                          f"same sample: {cpu_baseline['value']} Gbases/s on {cpu_baseline['cores']} cores"}
             sk2 = engine.Sketcher(args.k, args.s, args.m, expected_bytes=sample.size)
             sk2.push_device(fq.data_ptr(), n_s * rb, engine.FMT_FASTQ4)
             got, _ = sk2.finish()
