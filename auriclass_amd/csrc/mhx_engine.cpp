@@ -13,6 +13,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -521,7 +523,7 @@ static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
     }
 }
 
-extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
 {
     clear_error();
     int rc = require_engine();
@@ -556,7 +558,7 @@ extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t 
     return MHX_OK;
 }
 
-extern "C" int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts, uint32_t cap, uint32_t *n_out)
+static int mhx_sketcher_export_impl(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts, uint32_t cap, uint32_t *n_out)
 {
     clear_error();
     int rc = require_engine();
@@ -960,7 +962,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     return rc;
 }
 
-extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
+static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
                                 const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
                                 double *est_genome_size)
 {
@@ -1062,7 +1064,7 @@ extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, ui
     return put_text(err, stderr_buf, stderr_cap, stderr_need);
 }
 
-extern "C" int mhx_dist_files(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
+static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
 {
     clear_error();
     int rc = require_engine();
@@ -1120,4 +1122,50 @@ extern "C" int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_ref
         if (n_hashes[i]) set.refs[i].hashes.assign(hashes[i], hashes[i] + n_hashes[i]);
     }
     return msh_write_file(path, set);
+}
+
+extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
+                                const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
+                                double *est_genome_size)
+{
+    try {
+        return mhx_sketch_files_impl(paths, n_paths, k, s, reads, min_mult, out_msh, stderr_buf, stderr_cap, stderr_need, est_genome_size);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_sketch_files: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketch_files: %s", e.what());
+    }
+}
+
+extern "C" int mhx_dist_files(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
+{
+    try {
+        return mhx_dist_files_impl(ref_msh, qry_msh, stdout_buf, cap, need);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_dist_files: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_dist_files: %s", e.what());
+    }
+}
+
+extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+{
+    try {
+        return mhx_sketcher_finish_impl(sk, hashes, counts, n_out);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_finish: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_finish: %s", e.what());
+    }
+}
+
+extern "C" int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts, uint32_t cap, uint32_t *n_out)
+{
+    try {
+        return mhx_sketcher_export_impl(sk, limit, hashes, counts, cap, n_out);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_export: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_export: %s", e.what());
+    }
 }

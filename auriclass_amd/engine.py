@@ -228,11 +228,15 @@ class Sketcher:
         self._h = h
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            load().mhx_sketcher_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.mhx_sketcher_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:                      # the module globals may already be gone at interpreter shutdown
+            self.close()
+        except Exception:
+            pass
 
     def reset(self) -> None:
         _check(load().mhx_sketcher_reset(self._h))
