@@ -17,6 +17,7 @@
 #include <new>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -782,9 +783,11 @@ namespace {
 constexpr size_t kIngestChunk = 32u << 20;
 
 struct IngestChunk {
-    std::vector<uint8_t> data;
+    std::unique_ptr<uint8_t[]> buf; // kIngestChunk bytes, not zero-filled
+    size_t size = 0;
     int file = 0;
     bool first_of_file = false;
+    uint8_t *data() { return buf.get(); }
 };
 
 class ChunkQueue {
@@ -827,11 +830,41 @@ struct FileIngestState {
     bool not_fastq4 = false;
 };
 
+static bool is_gzip_file(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    uint8_t magic[2] = {0, 0};
+    if (f) { if (fread(magic, 1, 2, f) != 2) magic[0] = 0; fclose(f); }
+    return magic[0] == 0x1f && magic[1] == 0x8b;
+}
+
+static size_t count_newlines(const uint8_t *p, size_t n)
+{ // plain loop: the compiler vectorises it (several GB/s), unlike a memchr call per line
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+
 void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestState *st)
 {
-    gzFile g = gzopen(path, "rb");
-    if (!g) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
-    gzbuffer(g, 1 << 20);
+    const bool gz = is_gzip_file(path);
+    gzFile g = nullptr;
+    FILE *plain = nullptr;
+    uint64_t plain_size = 0;
+    if (gz) {
+        g = gzopen(path, "rb");
+        if (g) gzbuffer(g, 1 << 20);
+    } else {
+        plain = fopen(path, "rb");
+        struct stat sb;
+        if (plain && stat(path, &sb) == 0) plain_size = (uint64_t)sb.st_size;
+    }
+    if (!g && !plain) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
+    auto close_all = [&]() { if (g) gzclose(g); if (plain) fclose(plain); };
+    // large uncompressed inputs: a vectorised newline count finds the record boundary; records are then
+    // counted as lines / 4 (the per-line scan that also applies mash's "length >= k" rule to the
+    // '[N seqs]' comment costs more than everything else there; inflate hides it for .gz inputs)
+    const bool per_line = gz || (plain_size < (512ull << 20) && !getenv("MHX_INGEST_FAST"));
     std::vector<uint8_t> carry;
     bool first = true;
     uint64_t lines_before = 0; // newlines in everything already emitted
@@ -839,44 +872,57 @@ void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestS
         IngestChunk c;
         c.file = file;
         c.first_of_file = first;
-        c.data.resize(kIngestChunk);
+        c.buf.reset(new uint8_t[kIngestChunk]);
+        uint8_t *d = c.data();
         size_t n = carry.size();
-        if (n) memcpy(c.data.data(), carry.data(), n);
+        if (n) memcpy(d, carry.data(), n);
         carry.clear();
         bool eof = false;
         while (n < kIngestChunk) {
-            const int got = gzread(g, c.data.data() + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
-            if (got < 0) { st->error = std::string("ERROR: reading ") + path + " failed"; gzclose(g); q->producer_done(); return; }
+            long got;
+            if (gz) got = gzread(g, d + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
+            else { got = (long)fread(d + n, 1, kIngestChunk - n, plain); if (got == 0 && ferror(plain)) got = -1; }
+            if (got < 0) { st->error = std::string("ERROR: reading ") + path + " failed"; close_all(); q->producer_done(); return; }
             if (got == 0) { eof = true; break; }
             n += (size_t)got;
         }
-        if (first && n && c.data[0] != '@') { st->not_fastq4 = true; gzclose(g); q->producer_done(); return; }
+        if (first && n && d[0] != '@') { st->not_fastq4 = true; close_all(); q->producer_done(); return; }
         // cut after the last newline that completes a record (line count multiple of 4)
-        size_t cut = 0, tail_from = 0;
+        size_t cut = 0;
         uint64_t lines = lines_before, lines_at_cut = lines_before, counted = 0, counted_at_cut = 0;
-        for (size_t off = 0; off < n;) {
-            const uint8_t *p = (const uint8_t *)memchr(c.data.data() + off, '\n', n - off);
-            if (!p) { tail_from = off; break; }
-            const size_t len = (size_t)(p - c.data.data()) - off;
-            if ((lines & 3) == 1 && len >= (size_t)k) ++counted; // line index 1 of a record = its bases
-            ++lines;
-            off = (size_t)(p - c.data.data()) + 1;
-            tail_from = off;
-            if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; counted_at_cut = counted; }
+        if (per_line) {
+            for (size_t off = 0; off < n;) {
+                const uint8_t *p = (const uint8_t *)memchr(d + off, '\n', n - off);
+                if (!p) break;
+                const size_t len = (size_t)(p - d) - off;
+                if ((lines & 3) == 1 && len >= (size_t)k) ++counted; // line index 1 of a record = its bases
+                ++lines;
+                off = (size_t)(p - d) + 1;
+                if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; counted_at_cut = counted; }
+            }
+        } else {
+            lines = lines_before + count_newlines(d, n);
+            // step back over the newlines that belong to the unfinished last record
+            uint64_t back = lines & 3;
+            size_t end = n;
+            const uint8_t *p = (const uint8_t *)memrchr(d, '\n', end);
+            while (p && back) { end = (size_t)(p - d); p = (const uint8_t *)memrchr(d, '\n', end); --back; }
+            if (p) { cut = (size_t)(p - d) + 1; lines_at_cut = lines - (lines & 3); }
+            counted = (lines - lines_before) / 4;
+            counted_at_cut = (lines_at_cut - lines_before) / 4;
         }
         if (eof) {
             // the tail must be whole records; a last record may lack its final newline
             if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
             cut = n;
-            lines_at_cut = lines + (n && c.data[n - 1] != '\n' ? 1 : 0);
-            counted_at_cut = counted;
-            (void)tail_from;
+            lines_at_cut = lines + (n && d[n - 1] != '\n' ? 1 : 0);
+            counted_at_cut = per_line ? counted : (lines_at_cut - lines_before) / 4;
         } else if (cut == 0) {
             st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
         }
-        if (st->not_fastq4) { gzclose(g); q->producer_done(); return; }
-        if (cut < n) carry.assign(c.data.begin() + cut, c.data.begin() + n);
-        c.data.resize(cut);
+        if (st->not_fastq4) { close_all(); q->producer_done(); return; }
+        if (cut < n) carry.assign(d + cut, d + n);
+        c.size = cut;
         st->bytes += cut;
         st->lines = lines_at_cut;
         st->counted += counted_at_cut;
@@ -885,7 +931,7 @@ void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestS
         if (cut) q->put(std::move(c));
         if (eof || q->aborted()) break;
     }
-    gzclose(g);
+    close_all();
     q->producer_done();
 }
 
@@ -893,11 +939,7 @@ uint64_t guess_inflated_bytes(const char *path)
 {
     struct stat sb;
     if (stat(path, &sb) != 0) return 0;
-    FILE *f = fopen(path, "rb");
-    uint8_t magic[2] = {0, 0};
-    if (f) { if (fread(magic, 1, 2, f) != 2) magic[0] = 0; fclose(f); }
-    const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
-    return (uint64_t)sb.st_size * (gz ? 8 : 1);
+    return (uint64_t)sb.st_size * (is_gzip_file(path) ? 8 : 1);
 }
 } // namespace
 
@@ -925,11 +967,11 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     while (q.get(c)) {
         if (rc) continue; // drain
         if (c.first_of_file && (!have_header || c.file == 0)) {
-            first_header(c.data.data(), c.data.size(), *fname, *fcomment);
+            first_header(c.data(), c.size, *fname, *fcomment);
             have_header = true;
         }
-        if (hipMemcpyAsync(d_slot, c.data.data(), c.data.size(), hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
-        rc = mhx_sketcher_push_device(sk, d_slot, c.data.size(), MHX_FMT_FASTQ4);
+        if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
+        rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
         if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
         if (rc) q.abort();
     }

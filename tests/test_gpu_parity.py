@@ -424,3 +424,21 @@ def test_many_pushes_far_beyond_the_expected_size_stay_exact():
         want, _ = ref.finish()
         assert np.array_equal(got, want)
         assert st["flags"] == 0
+
+
+def test_streaming_ingest_fast_plain_file_path(tmp_path, monkeypatch):
+    """Large uncompressed FASTQ files take the vectorised-newline-count path (record cut by counting
+    back from the chunk end); forced here on a 100 MB file with a ragged tail."""
+    monkeypatch.setenv("MHX_INGEST_FAST", "1")
+    genome = synth.make_genome(300_000, seed=18)
+    a = synth.make_fastq(genome, 330_000, 150, seed=19, device="cpu").numpy().tobytes()     # 104 MB -> 4 chunks
+    a += b"@tail\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII"            # no final newline
+    p = tmp_path / "big.fq"
+    p.write_bytes(a)
+    engine.sketch_files([p], 21, 3000, tmp_path / "b.msh", reads=True, min_mult=2)
+    ref = mo.Sketcher(21, 3000, 2)
+    ref.add_fastx(a)
+    want, _ = ref.finish()
+    got = mo.read_msh(tmp_path / "b.msh").references[0]
+    assert np.array_equal(got.hashes, want)
+    assert got.comment == "[330001 seqs] r00000000  [...]"
