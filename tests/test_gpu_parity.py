@@ -442,3 +442,26 @@ def test_streaming_ingest_fast_plain_file_path(tmp_path, monkeypatch):
     got = mo.read_msh(tmp_path / "b.msh").references[0]
     assert np.array_equal(got.hashes, want)
     assert got.comment == "[330001 seqs] r00000000  [...]"
+
+
+@pytest.mark.parametrize("k", [16, 21, 27, 32])
+def test_strand_decision_exact_path_on_device(k):
+    """Windows whose first 8 bases equal those of their reverse complement leave the fast 8-base strand
+    comparison and take the exact dword-by-dword one (rare branch: forced here on every window)."""
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    rng = np.random.default_rng(500 + k)
+    reads = []
+    for _ in range(4000):
+        x = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=8)
+        mid = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=k - 16)
+        kmer = np.concatenate([x, mid, np.array([comp[int(c)] for c in x[::-1]], np.uint8)])
+        left = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 10)))
+        right = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 10)))
+        reads.append(bytes(np.concatenate([left, kmer, right])))
+    data = b"\n".join(reads) + b"\n"
+    sk = engine.Sketcher(k, 5000, 1, expected_bytes=len(data))
+    sk.push_host(data, engine.FMT_SEQ)
+    got, cnt = sk.finish()
+    sk.close()
+    want, wcnt = mo.bruteforce_sketch(reads, k, 5000, 1)
+    assert np.array_equal(got, want) and np.array_equal(cnt, wcnt)
