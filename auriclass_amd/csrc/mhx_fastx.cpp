@@ -75,7 +75,10 @@ int parse_fastx(const uint8_t *buf, size_t n, int k, ParsedRecords &out)
     while (p < n) {
         // header
         size_t e = p + 1;
-        while (e < n && buf[e] != '\n') ++e;
+        {
+            const uint8_t *nl = e < n ? (const uint8_t *)memchr(buf + e, '\n', n - e) : nullptr;
+            e = nl ? (size_t)(nl - buf) : n;
+        }
         const size_t hdr_begin = p + 1;
         size_t hdr_end = e;
         if (hdr_end > hdr_begin && buf[hdr_end - 1] == '\r') --hdr_end;
@@ -83,11 +86,20 @@ int parse_fastx(const uint8_t *buf, size_t n, int k, ParsedRecords &out)
         // sequence lines
         const size_t seq_start = out.seq.size();
         while (p < n && buf[p] != '>' && buf[p] != '@' && buf[p] != '+') {
-            size_t le = p;
-            while (le < n && buf[le] != '\n') ++le;
-            for (size_t q = p; q < le; ++q) {
-                const uint8_t c = buf[q];
-                if (c > ' ' && c != 127) out.seq.push_back(c);
+            const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', n - p);
+            const size_t le = nl ? (size_t)(nl - buf) : n;
+            // append the line in bulk; blanks / control bytes (rare) are squeezed out afterwards
+            const size_t at = out.seq.size();
+            out.seq.insert(out.seq.end(), buf + p, buf + le);
+            unsigned dirty = 0;
+            for (size_t q = p; q < le; ++q) dirty |= (unsigned)(buf[q] <= ' ') | (unsigned)(buf[q] == 127);
+            if (dirty) {
+                size_t w = at;
+                for (size_t q = at; q < out.seq.size(); ++q) {
+                    const uint8_t c = out.seq[q];
+                    if (c > ' ' && c != 127) out.seq[w++] = c;
+                }
+                out.seq.resize(w);
             }
             p = le < n ? le + 1 : n;
         }
