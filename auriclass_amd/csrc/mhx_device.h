@@ -33,6 +33,7 @@ struct TableArgs {
     uint64_t *stats;
     uint32_t min_mult;
     uint32_t sketch_size;
+    uint32_t sample;     // tighten pass looks at one 256-slot block in `sample` (1 = exact pass)
 };
 
 // launchers (mhx_kernels.hip)

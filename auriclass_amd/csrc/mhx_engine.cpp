@@ -164,6 +164,7 @@ static TableArgs table_args(mhx_sketcher *sk)
     TableArgs t;
     t.keys = sk->d_keys; t.cnts = sk->d_cnts; t.nslots = sk->nslots; t.thresh = sk->d_thresh;
     t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.min_mult = sk->m; t.sketch_size = sk->s;
+    t.sample = 1;
     return t;
 }
 
@@ -323,7 +324,8 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         HIPCHK(hipMemsetAsync(sk->d_tickets, 0, kMaxLaunchesPerPush * sizeof(uint32_t), g.stream));
     }
     a.tile_state = sk->d_tile_state;
-    const TableArgs ta = table_args(sk);
+    TableArgs ta = table_args(sk);
+    if (sk->nslots >= (1ull << 23) && !getenv("MHX_EXACT_TIGHTEN")) ta.sample = 8; // big tables: sampled passes between chunks
     uint32_t tile = 0;
     int launch = 0;
     while (tile < ntiles) {

@@ -264,7 +264,12 @@ __global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
     const uint64_t T = *a.thresh;
     const int lz = T ? __builtin_clzll(T) : 63;
     uint32_t occ = 0, solid = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+    // sample = 1: every slot; sample = 8: one 256-slot block in eight (slots are hash-addressed, so
+    // any fixed subset of blocks is a uniform sample of the entries)
+    const uint64_t nblocks256 = a.nslots / 256;
+    const uint64_t step = a.sample > 1 ? a.sample : 1;
+    for (uint64_t b = (uint64_t)blockIdx.x * step; b < nblocks256; b += (uint64_t)gridDim.x * step) {
+        const uint64_t i = b * 256 + threadIdx.x;
         const uint64_t key = a.keys[i];
         if (key == kEmptyKey) continue;
         ++occ;
@@ -297,15 +302,17 @@ __global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
     uint32_t before = 0;
     for (int i = 0; i < t; ++i) before += part[i];
     __syncthreads();
-    const uint32_t s = a.sketch_size;
+    // sampled pass: counts are 1/sample of the truth; ask for twice the sketch size so that the
+    // sampling error cannot push T below the true s-th qualifying hash (finish() re-checks exactly)
+    const uint32_t s = a.sample > 1 ? (2 * a.sketch_size + a.sample - 1) / a.sample + 16 : a.sketch_size;
     if (before < s && before + c0 >= s) atomicMin(&cut, (uint32_t)(2 * t));
     else if (before + c0 < s && before + c0 + c1 >= s) atomicMin(&cut, (uint32_t)(2 * t + 1));
     a.hist[2 * t] = 0;
     a.hist[2 * t + 1] = 0;
     __syncthreads();
     if (t == 0) { // publish this pass's totals (replica 0), clear the accumulators
-        a.stats[kStatOccupied] = a.acc[0];
-        a.stats[kStatSolid] = a.acc[1];
+        a.stats[kStatOccupied] = a.acc[0] * (a.sample > 1 ? a.sample : 1);
+        a.stats[kStatSolid] = a.acc[1] * (a.sample > 1 ? a.sample : 1);
         a.acc[0] = 0;
         a.acc[1] = 0;
     }
@@ -321,8 +328,10 @@ __global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
 
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st)
 {
-    uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 2048) blocks = 2048;
+    // few, long-running workgroups: each one flushes its 2048-bin LDS histogram with global atomics
+    uint64_t blocks = a.nslots / 256 / 16;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(table_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(table_select_kernel, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
@@ -332,13 +341,43 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
                                                             uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
                                                             uint32_t *out_n)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nslots; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = a.keys[i];
-        if (key == kEmptyKey || key > limit) continue;
-        const uint32_t c = a.cnts[i];
-        if (c < min_count) continue;
-        const uint32_t pos = atomicAdd(out_n, 1u);
-        if (pos < cap) { out_keys[pos] = key; out_cnts[pos] = c; }
+    // Qualifying entries are sparse (about one per few hundred slots), so they are collected per
+    // workgroup in LDS and appended to the output with ONE global atomic per flush instead of one
+    // per entry (a single counter word serialises at ~10 ns per atomic).
+    constexpr uint32_t kBuf = 1024;
+    __shared__ unsigned long long bkeys[kBuf];
+    __shared__ uint32_t bcnts[kBuf];
+    __shared__ uint32_t nbuf, base;
+    if (threadIdx.x == 0) nbuf = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (a.nslots + stride - 1) / stride; // same trip count for every thread (barriers inside)
+    for (uint64_t rd = 0; rd <= rounds; ++rd) {
+        if (rd < rounds) {
+            const uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            if (i < a.nslots) {
+                const uint64_t key = a.keys[i];
+                if (key != kEmptyKey && key <= limit) {
+                    const uint32_t c = a.cnts[i];
+                    if (c >= min_count) {
+                        const uint32_t p = atomicAdd(&nbuf, 1u); // at most 256 per round, flushed below before it can overflow
+                        bkeys[p] = key;
+                        bcnts[p] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = nbuf;
+        if (n > kBuf - 256 || (rd == rounds && n)) { // flush
+            if (threadIdx.x == 0) base = atomicAdd(out_n, n);
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
+                if (base + j < cap) { out_keys[base + j] = bkeys[j]; out_cnts[base + j] = bcnts[j]; }
+            __syncthreads();
+            if (threadIdx.x == 0) nbuf = 0;
+            __syncthreads();
+        }
     }
 }
 
