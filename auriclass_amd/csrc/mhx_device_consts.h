@@ -7,7 +7,7 @@ namespace mhx {
 
 // ---- tile geometry of the sketch kernel ------------------------------------------------
 #ifndef MHX_TILE_BYTES
-#define MHX_TILE_BYTES 32768
+#define MHX_TILE_BYTES 16384
 #endif
 constexpr int kTileBytes = MHX_TILE_BYTES;           // bytes of the stream one workgroup owns
 constexpr int kHaloBytes = 64;                       // staged beyond the tile (>= 8 + 32)
@@ -16,7 +16,7 @@ constexpr int kHaloBytes = 64;                       // staged beyond the tile (
 #endif
 constexpr int kBlock = MHX_BLOCK;                    // threads per workgroup
 constexpr int kGroup = 8;                            // k-mer start positions per work item
-constexpr int kGroupsPerTile = kTileBytes / kGroup;  // 4096
+constexpr int kGroupsPerTile = kTileBytes / kGroup;  // 2048
 constexpr int kBytesPerThread = kTileBytes / kBlock; // 128
 constexpr int kWordsPerThread = kBytesPerThread / 32; // 32-byte words classified per thread
 static_assert(kBytesPerThread % 32 == 0 && kTileBytes % (16 * kBlock) == 0, "tile geometry");

@@ -1,6 +1,6 @@
 // mhx_kernels.hip -- gfx950 kernels of the sketch + distance engine.
 //
-//   sketch_tile_kernel<K,FMT>  one workgroup per 32 KiB tile of the FASTQ / sequence byte
+//   sketch_tile_kernel<K,FMT>  one workgroup per 16 KiB tile of the FASTQ / sequence byte
 //                              stream: stage -> classify -> (FASTQ) decoupled look-back for
 //                              the line phase -> valid k-mer starts -> LDS work list ->
 //                              canonical k-mer + MurmurHash3_x64_128 -> admission -> table

@@ -5,7 +5,7 @@
 //
 // What one tile does (replaces mash's kseq_read + addMinHashes + getHash hot loop,
 // Mash 2.x Sketch.cpp; reached from /root/reference/auriclass/classes.py:576-596,696-713):
-//   stage     32 KiB (+64 B halo) of the byte stream into LDS, 16 B per lane, coalesced
+//   stage     16 KiB (+64 B halo) of the byte stream into LDS, 16 B per lane, coalesced
 //   classify  per byte: newline?  A/C/G/T (either case)?        -> bit masks (SIMD-in-register)
 //   phase     FASTQ: newline prefix -> line number mod 4 == 1 marks sequence lines
 //   runs      valid k-mer starts = runs of >= K good bytes       -> 1 bit per position
@@ -79,6 +79,14 @@ MHX_HD uint32_t funnel(uint32_t hi, uint32_t lo, int byte_shift)
 #else
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * byte_shift));
 #endif
+}
+// value the optimiser must treat as unknown at this point (pins cold-path work behind its branch)
+MHX_HD uint32_t opaque(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
 }
 MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
 { // bit_shift in 0..31
@@ -229,7 +237,7 @@ template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
 MHX_HD void phase_stage(TileSmem &sm, int tid, const uint8_t *base, uint64_t tile_off, uint64_t end)
 {
     const uint64_t lim = (end + 15) & ~(uint64_t)15; // last readable 16-byte chunk boundary
-    constexpr int kChunks = kTileBytes / 16;          // 2048
+    constexpr int kChunks = kTileBytes / 16;          // 1024
 #pragma unroll
     for (int j = 0; j < kChunks / kBlock; ++j) {
         const int c = j * kBlock + tid;
@@ -405,9 +413,15 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
         const uint64_t top_r = load64<J + K - 8>(Cc);
         bool rc = top_r < top_f;
         if (K > 8 && top_r == top_f) { // cold: exact comparison
+            // the copies go through an opaque barrier so that the compiler cannot hoist the
+            // word extraction of this 4^-8 case in front of the branch (it did: ~19 wasted
+            // instructions per window on the hot path)
+            uint32_t Uc[ND + 1], Rc[ND + 1];
+#pragma unroll
+            for (int i = 0; i < ND + 1; ++i) { Uc[i] = opaque(U[i]); Rc[i] = opaque(R[i]); }
             uint32_t wf[8], wr[8];
-            extract_words<K, OF>(U, wf);
-            extract_words<K, OR>(R, wr);
+            extract_words<K, OF>(Uc, wf);
+            extract_words<K, OR>(Rc, wr);
             rc = rc_is_smaller_full<NW>(wf, wr);
         }
         // select the source dwords first, extract once
@@ -432,13 +446,15 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
 
 // P5: one work item = 8 consecutive window starts sharing one register chunk.
 // ins(h) is called for every valid window whose hash is <= T.
+template <int K> struct GroupGeom {
+    static constexpr int NB = kGroup + K - 1; // bytes touched
+    static constexpr int ND = (NB + 3) / 4;   // dwords loaded
+};
+
 template <int K, class Ins>
-MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool hash32, Ins &ins)
+MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint32_t vm, uint64_t T, Ins &ins)
 {
-    constexpr int NB = kGroup + K - 1; // bytes touched
-    constexpr int ND = (NB + 3) / 4;   // dwords loaded
-    const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
+    constexpr int ND = GroupGeom<K>::ND;
     uint32_t U[ND + 1], R[ND + 1], Wr[ND + 1], Cc[ND + 1];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
@@ -452,7 +468,6 @@ MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool h
     }
     U[ND] = R[ND] = Wr[ND] = Cc[ND] = 0;
     constexpr bool kHash32 = K <= 16; // mash keeps 32 bits when 4^k <= 2^32
-    (void)hash32;
 #ifndef MHX_BATCH_ADMIT
 #define MHX_BATCH_ADMIT 0
 #endif
@@ -494,6 +509,20 @@ MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool h
 #endif
     static_assert(kGroup == 8, "process_group unrolls 8 windows");
     return ninserted;
+}
+
+// work item g of a staged tile (LDS source)
+template <int K, class Ins>
+MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool hash32, Ins &ins)
+{
+    constexpr int ND = GroupGeom<K>::ND;
+    (void)hash32;
+    const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
+    uint32_t src[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) src[d] = p[d];
+    return process_group_regs<K>(src, vm, T, ins);
 }
 
 } // namespace mhx
