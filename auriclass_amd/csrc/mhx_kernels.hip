@@ -73,38 +73,53 @@ __device__ uint32_t lookback_wave(uint64_t *state, uint32_t tile, uint32_t first
     if (lane == 0) st_state(&state[tile], A | agg);
     uint32_t excl = 0;
     int64_t pos = (int64_t)tile - 1;
-    for (uint32_t spins = 0;;) {
-        const int64_t idx = pos - lane;
-        const uint64_t w = idx >= (int64_t)first_tile ? ld_state(&state[idx]) : P; // before the push: prefix 0
-        const uint32_t f = (uint32_t)(w >> 32);
-        const uint64_t notready = __ballot(f == 0);
-        const uint64_t isp = __ballot(f == 2);
-        uint64_t take = 0; // lanes whose value is added
-        bool done = false;
-        if (isp) {
-            const int j = __builtin_ctzll(isp);
-            const uint64_t below = j ? (~0ull >> (64 - j)) : 0ull;
-            if ((notready & below) == 0) {
-                take = below | (1ull << j);
-                done = true;
-            }
-        } else if (!notready) {
-            take = ~0ull;
-        }
-        if (take) {
-            uint32_t v = ((take >> lane) & 1ull) ? (uint32_t)w : 0u;
+    // Every round polls the 4 x 64 nearest unread predecessors with four loads in flight at once:
+    // tiles reach this point faster than one L2 round trip per 64 of them, so a 64-wide window
+    // per round trip never catches up with the newest published prefix.
+    constexpr int kWin = 4;
+    bool done = false;
+    for (uint32_t spins = 0; !done;) {
+        uint64_t w[kWin];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            excl += v;
-            if (done) break;
-            pos -= 64;
-            continue;
+        for (int j = 0; j < kWin; ++j) {
+            const int64_t idx = pos - lane - 64 * j;
+            w[j] = idx >= (int64_t)first_tile ? ld_state(&state[idx]) : P; // before the push: prefix 0
         }
-        if (++spins > (1u << 20)) { // ~a second; never reached in a healthy launch
-            if (lane == 0) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagSpinTimeout);
-            break;
+        bool blocked = false;
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+            if (done || blocked) continue;
+            const uint32_t f = (uint32_t)(w[j] >> 32);
+            const uint64_t notready = __ballot(f == 0);
+            const uint64_t isp = __ballot(f == 2);
+            uint64_t take = 0; // lanes whose value is added
+            if (isp) {
+                const int q = __builtin_ctzll(isp);
+                const uint64_t below = q ? (~0ull >> (64 - q)) : 0ull;
+                if ((notready & below) == 0) {
+                    take = below | (1ull << q);
+                    done = true;
+                }
+            } else if (!notready) {
+                take = ~0ull;
+            }
+            if (take) {
+                uint32_t v = ((take >> lane) & 1ull) ? (uint32_t)w[j] : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                excl += v;
+                if (!done) pos -= 64;
+            } else {
+                blocked = true;
+            }
         }
-        __builtin_amdgcn_s_sleep(4);
+        if (blocked) {
+            if (++spins > (1u << 20)) { // ~a second; never reached in a healthy launch
+                if (lane == 0) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagSpinTimeout);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
     }
     if (lane == 0) st_state(&state[tile], P | (uint64_t)(excl + agg));
     return excl;
