@@ -36,6 +36,7 @@ enum Stat : int {
     kStatMaxKey = 4,  // occurrences of the hash value 2^64-1 (cannot live in the table)
     kStatOccupied = 5,
     kStatSolid = 6,   // entries <= T with count >= m seen by the last tighten pass
+    kStatRecords = 7, // FASTQ records whose sequence line holds >= k bytes (mash's sequence count)
     kStatStamp0 = 8,  // diagnostic builds (-DMHX_STAMPS): cycles per phase, summed over workgroups
     kStatCount = 16
 };

@@ -8,7 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <zlib.h>
 
@@ -58,6 +60,11 @@ struct Engine {
     double last_dist_ms = 0.0;
     uint8_t *dist_ws = nullptr; // workspace of the all-vs-refs distance path
     size_t dist_ws_cap = 0;
+    // bulk file ingest: pinned staging ring + copy stream (allocated on first use, kept)
+    static constexpr int kPinnedSlots = 4;
+    uint8_t *pinned[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pinned_free[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
 };
 static Engine g;
 
@@ -98,6 +105,12 @@ extern "C" void mhx_shutdown(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     hipFree(g.dist_ws);
+    if (g.copy_stream) hipStreamSynchronize(g.copy_stream);
+    for (int i = 0; i < Engine::kPinnedSlots; ++i) {
+        if (g.pinned[i]) hipHostFree(g.pinned[i]);
+        if (g.pinned_free[i]) hipEventDestroy(g.pinned_free[i]);
+    }
+    if (g.copy_stream) hipStreamDestroy(g.copy_stream);
     hipEventDestroy(g.ev0);
     hipEventDestroy(g.ev1);
     hipStreamDestroy(g.stream);
@@ -409,6 +422,7 @@ static int fetch_stats(mhx_sketcher *sk, uint64_t *sum)
         sum[kStatKmers] += h[r * kStatCount + kStatKmers];
         sum[kStatInserts] += h[r * kStatCount + kStatInserts];
         sum[kStatLines] += h[r * kStatCount + kStatLines];
+        sum[kStatRecords] += h[r * kStatCount + kStatRecords];
         sum[kStatMaxKey] += h[r * kStatCount + kStatMaxKey];
         sum[kStatFlags] |= h[r * kStatCount + kStatFlags];
     }
@@ -439,6 +453,19 @@ extern "C" int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8)
 }
 
 // diagnostic: raw per-phase cycle sums of a -DMHX_STAMPS build (zeros otherwise)
+extern "C" int mhx_sketcher_record_count(mhx_sketcher *sk, uint64_t *records)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !records) return fail(MHX_E_ARG, "null argument");
+    uint64_t s[kStatCount];
+    rc = fetch_stats(sk, s);
+    if (rc) return rc;
+    *records = s[kStatRecords];
+    return MHX_OK;
+}
+
 extern "C" int mhx_sketcher_debug_stamps(mhx_sketcher *sk, uint64_t *out8)
 {
     clear_error();
@@ -847,26 +874,19 @@ static size_t count_newlines(const uint8_t *p, size_t n)
     return c;
 }
 
-void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestState *st)
+void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *st)
 {
     const bool gz = is_gzip_file(path);
     gzFile g = nullptr;
     FILE *plain = nullptr;
-    uint64_t plain_size = 0;
     if (gz) {
         g = gzopen(path, "rb");
         if (g) gzbuffer(g, 1 << 20);
     } else {
         plain = fopen(path, "rb");
-        struct stat sb;
-        if (plain && stat(path, &sb) == 0) plain_size = (uint64_t)sb.st_size;
     }
     if (!g && !plain) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
     auto close_all = [&]() { if (g) gzclose(g); if (plain) fclose(plain); };
-    // large uncompressed inputs: a vectorised newline count finds the record boundary; records are then
-    // counted as lines / 4 (the per-line scan that also applies mash's "length >= k" rule to the
-    // '[N seqs]' comment costs more than everything else there; inflate hides it for .gz inputs)
-    const bool per_line = gz || (plain_size < (512ull << 20) && !getenv("MHX_INGEST_FAST"));
     std::vector<uint8_t> carry;
     bool first = true;
     uint64_t lines_before = 0; // newlines in everything already emitted
@@ -890,35 +910,22 @@ void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestS
         }
         if (first && n && d[0] != '@') { st->not_fastq4 = true; close_all(); q->producer_done(); return; }
         // cut after the last newline that completes a record (line count multiple of 4)
+        // (a vectorised newline count, then a short walk back over the unfinished last record;
+        // the records themselves are parsed and counted on the device)
         size_t cut = 0;
-        uint64_t lines = lines_before, lines_at_cut = lines_before, counted = 0, counted_at_cut = 0;
-        if (per_line) {
-            for (size_t off = 0; off < n;) {
-                const uint8_t *p = (const uint8_t *)memchr(d + off, '\n', n - off);
-                if (!p) break;
-                const size_t len = (size_t)(p - d) - off;
-                if ((lines & 3) == 1 && len >= (size_t)k) ++counted; // line index 1 of a record = its bases
-                ++lines;
-                off = (size_t)(p - d) + 1;
-                if ((lines & 3) == 0) { cut = off; lines_at_cut = lines; counted_at_cut = counted; }
-            }
-        } else {
-            lines = lines_before + count_newlines(d, n);
-            // step back over the newlines that belong to the unfinished last record
+        uint64_t lines = lines_before + count_newlines(d, n), lines_at_cut = lines_before;
+        {
             uint64_t back = lines & 3;
             size_t end = n;
             const uint8_t *p = (const uint8_t *)memrchr(d, '\n', end);
             while (p && back) { end = (size_t)(p - d); p = (const uint8_t *)memrchr(d, '\n', end); --back; }
             if (p) { cut = (size_t)(p - d) + 1; lines_at_cut = lines - (lines & 3); }
-            counted = (lines - lines_before) / 4;
-            counted_at_cut = (lines_at_cut - lines_before) / 4;
         }
         if (eof) {
             // the tail must be whole records; a last record may lack its final newline
             if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
             cut = n;
             lines_at_cut = lines + (n && d[n - 1] != '\n' ? 1 : 0);
-            counted_at_cut = per_line ? counted : (lines_at_cut - lines_before) / 4;
         } else if (cut == 0) {
             st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
         }
@@ -927,7 +934,6 @@ void inflate_fastq(const char *path, int file, int k, ChunkQueue *q, FileIngestS
         c.size = cut;
         st->bytes += cut;
         st->lines = lines_at_cut;
-        st->counted += counted_at_cut;
         lines_before = lines_at_cut;
         first = false;
         if (cut) q->put(std::move(c));
@@ -945,6 +951,115 @@ uint64_t guess_inflated_bytes(const char *path)
 }
 } // namespace
 
+// ---- bulk ingest of an uncompressed FASTQ file -------------------------------------------
+// The whole file goes into ONE device buffer and ONE push: reader threads pread() disjoint
+// ranges of a 64 MiB block into a pinned staging slot, the block is copied to its place in the
+// device buffer on a copy stream while the next block is being read, and the device parser
+// finds the records itself (line phase by look-back), so the host never scans the bytes.
+namespace {
+constexpr size_t kBulkBlock = 64u << 20;
+
+struct BulkFile {
+    uint8_t *d_buf = nullptr;
+    uint64_t size = 0;
+    std::vector<uint8_t> head; // first bytes of the file (record name / comment)
+};
+
+static int ensure_pinned_ring()
+{
+    if (!g.copy_stream) HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < Engine::kPinnedSlots; ++i) {
+        if (!g.pinned[i]) HIPCHK(hipHostMalloc((void **)&g.pinned[i], kBulkBlock, hipHostMallocDefault));
+        if (!g.pinned_free[i]) HIPCHK(hipEventCreateWithFlags(&g.pinned_free[i], hipEventDisableTiming));
+    }
+    return MHX_OK;
+}
+
+// reads [off, off + len) of fd into dst with `nthreads` parallel preads; false on a short read
+static bool parallel_pread(int fd, uint8_t *dst, uint64_t off, size_t len, int nthreads)
+{
+    std::vector<std::thread> th;
+    std::vector<int> ok((size_t)nthreads, 1);
+    const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
+    for (int t = 0; t < nthreads; ++t) {
+        const size_t b = (size_t)t * per;
+        if (b >= len) break;
+        const size_t e = std::min(len, b + per);
+        th.emplace_back([=, &ok]() {
+            size_t done = b;
+            while (done < e) {
+                const ssize_t got = pread(fd, dst + done, e - done, (off_t)(off + done));
+                if (got <= 0) { ok[(size_t)t] = 0; return; }
+                done += (size_t)got;
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int v : ok) if (!v) return false;
+    return true;
+}
+
+// MHX_OK and f->d_buf set, or MHX_OK with d_buf == nullptr when the file should take another path
+static int bulk_load_plain(const char *path, BulkFile *f)
+{
+    struct stat sb;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) return MHX_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MHX_OK;
+    if ((uint64_t)sb.st_size + (4ull << 30) > free_b / 2) return MHX_OK; // leave room for tables and other files
+    int rc = ensure_pinned_ring();
+    if (rc) return rc;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
+    f->size = (uint64_t)sb.st_size;
+    if (hipMalloc((void **)&f->d_buf, f->size + 64) != hipSuccess) { close(fd); f->d_buf = nullptr; return MHX_OK; }
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 1) nthreads = 1;
+    uint64_t off = 0;
+    int slot = 0;
+    rc = MHX_OK;
+    while (off < f->size && !rc) {
+        const size_t len = (size_t)std::min<uint64_t>(kBulkBlock, f->size - off);
+        if (hipEventSynchronize(g.pinned_free[slot]) != hipSuccess) { rc = fail(MHX_E_HIP, "pinned slot wait failed"); break; }
+        if (!parallel_pread(fd, g.pinned[slot], off, len, len >= (8u << 20) ? nthreads : 1)) { rc = fail(MHX_E_IO, "ERROR: reading %s failed", path); break; }
+        if (off == 0) f->head.assign(g.pinned[slot], g.pinned[slot] + std::min<size_t>(len, 1u << 20));
+        if (hipMemcpyAsync(f->d_buf + off, g.pinned[slot], len, hipMemcpyHostToDevice, g.copy_stream) != hipSuccess ||
+            hipEventRecord(g.pinned_free[slot], g.copy_stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); break; }
+        off += len;
+        slot = (slot + 1) % Engine::kPinnedSlots;
+    }
+    close(fd);
+    if (!rc && hipMemsetAsync(f->d_buf + f->size, 0, 64, g.copy_stream) != hipSuccess) rc = fail(MHX_E_HIP, "memset failed");
+    if (!rc && hipStreamSynchronize(g.copy_stream) != hipSuccess) rc = fail(MHX_E_HIP, "copy stream sync failed");
+    if (rc) { hipStreamSynchronize(g.copy_stream); hipFree(f->d_buf); f->d_buf = nullptr; }
+    return rc;
+}
+
+// name / comment of the first record mash would count (sequence of at least k bytes); falls back to
+// the first header when none of the records in `buf` is long enough
+static void first_counted_header(const uint8_t *buf, size_t n, int k, std::string &name, std::string &comment)
+{
+    size_t p = 0;
+    while (p < n) {
+        const uint8_t *h_end = (const uint8_t *)memchr(buf + p, '\n', n - p);
+        if (!h_end) break;
+        const size_t s0 = (size_t)(h_end - buf) + 1;
+        const uint8_t *s_end = s0 < n ? (const uint8_t *)memchr(buf + s0, '\n', n - s0) : nullptr;
+        const size_t s1 = s_end ? (size_t)(s_end - buf) : n;
+        if (s1 - s0 >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return; }
+        // skip the '+' and quality lines
+        size_t q = s1 + 1;
+        for (int i = 0; i < 2 && q < n; ++i) {
+            const uint8_t *e = (const uint8_t *)memchr(buf + q, '\n', n - q);
+            q = e ? (size_t)(e - buf) + 1 : n;
+        }
+        p = q;
+    }
+    first_header(buf, n, name, comment);
+}
+} // namespace
+
 // returns MHX_OK with *handled = true when the streaming path produced the sketch;
 // *handled = false means "not strict FASTQ / could not size": use the whole-file path.
 static int stream_fastq_reference(const char *const *paths, int n_paths, int k, uint32_t s, uint32_t m, std::vector<uint64_t> &hashes,
@@ -957,33 +1072,51 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     mhx_sketcher *sk = nullptr;
     int rc = mhx_sketcher_create(k, s, m, expected, &sk);
     if (rc) return rc;
-    uint8_t *d_slot = nullptr;
-    if (hipMalloc((void **)&d_slot, kIngestChunk + 64) != hipSuccess) { mhx_sketcher_destroy(sk); return fail(MHX_E_HIP, "hipMalloc failed for the ingest slot"); }
-    ChunkQueue q;
-    std::vector<FileIngestState> st(n_paths);
-    std::vector<std::thread> threads;
-    for (int i = 0; i < n_paths; ++i) q.producer_started();
-    for (int i = 0; i < n_paths; ++i) threads.emplace_back(inflate_fastq, paths[i], i, k, &q, &st[i]);
-    IngestChunk c;
-    bool have_header = false;
-    while (q.get(c)) {
-        if (rc) continue; // drain
-        if (c.first_of_file && (!have_header || c.file == 0)) {
-            first_header(c.data(), c.size, *fname, *fcomment);
+    bool fallback = false, have_header = false;
+    // 1. uncompressed files: whole file -> one device buffer -> one push (see bulk_load_plain)
+    std::vector<int> queued; // files that go through an inflate thread instead
+    for (int i = 0; i < n_paths && !rc && !fallback; ++i) {
+        if (is_gzip_file(paths[i]) || getenv("MHX_NO_BULK")) { queued.push_back(i); continue; }
+        BulkFile bf;
+        rc = bulk_load_plain(paths[i], &bf);
+        if (rc) break;
+        if (!bf.d_buf) { queued.push_back(i); continue; }
+        if (bf.head.empty() || bf.head[0] != '@') fallback = true;
+        if (!fallback && (!have_header || i == 0)) {
+            first_counted_header(bf.head.data(), bf.head.size(), k, *fname, *fcomment);
             have_header = true;
         }
-        if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
-        rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
-        if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
-        if (rc) q.abort();
+        if (!fallback) rc = mhx_sketcher_push_device(sk, bf.d_buf, bf.size, MHX_FMT_FASTQ4);
+        if (hipStreamSynchronize(g.stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "stream sync failed");
+        hipFree(bf.d_buf);
     }
-    for (auto &t : threads) t.join();
-    bool fallback = false;
-    uint64_t total_counted = 0;
+    // 2. compressed files: one inflate thread per file, 32 MiB record-aligned chunks
+    uint8_t *d_slot = nullptr;
+    if (!rc && !fallback && !queued.empty() && hipMalloc((void **)&d_slot, kIngestChunk + 64) != hipSuccess)
+        rc = fail(MHX_E_HIP, "hipMalloc failed for the ingest slot");
+    std::vector<FileIngestState> st(n_paths);
+    if (!rc && !fallback && !queued.empty()) {
+        ChunkQueue q;
+        std::vector<std::thread> threads;
+        for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
+        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, &q, &st[i]);
+        IngestChunk c;
+        while (q.get(c)) {
+            if (rc) continue; // drain
+            if (c.first_of_file && (!have_header || c.file == 0)) {
+                first_counted_header(c.data(), std::min<size_t>(c.size, 1u << 20), k, *fname, *fcomment);
+                have_header = true;
+            }
+            if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
+            rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
+            if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
+            if (rc) q.abort();
+        }
+        for (auto &t : threads) t.join();
+    }
     for (auto &f : st) {
         if (!f.error.empty() && !rc) rc = fail(MHX_E_IO, "%s", f.error.c_str());
         if (f.not_fastq4) fallback = true;
-        total_counted += f.counted;
     }
     uint32_t n = 0;
     if (!rc && !fallback) {
@@ -996,10 +1129,10 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         uint64_t stt[8];
         rc = mhx_sketcher_stats(sk, stt);
         *kmers = stt[0];
-        *records = total_counted;
+        if (!rc) rc = mhx_sketcher_record_count(sk, records); // sequences of >= k bytes, counted by the device parser
         hashes.resize(n);
         counts.resize(n);
-        *handled = true;
+        *handled = !rc;
     }
     hipFree(d_slot);
     mhx_sketcher_destroy(sk);

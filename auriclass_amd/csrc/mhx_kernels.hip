@@ -173,7 +173,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     }
     const uint64_t tile_off = (uint64_t)tile * kTileBytes;
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(a.stats) + (tile % kStatReplicas) * kStatCount;
-    if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; }
+    if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; sm.misc[5] = 0; }
 #ifdef MHX_STAMPS
     uint64_t stamp_prev = clock64();
     int stamp_idx = 0;
@@ -213,8 +213,9 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     // the format look-ahead may only read staged bytes that belong to the span
     const uint64_t span_left = a.end > tile_off ? a.end - tile_off : 0;
     const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
-    phase_good<FASTQ>(sm, tid, st, line_base, excl, tile_total, check_limit, bad);
+    const uint32_t long_records = phase_good<FASTQ>(sm, tid, st, line_base, excl, tile_total, check_limit, bad, tile_off, a.end, (uint32_t)K);
     if (FASTQ && bad) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagBadFastq);
+    if (FASTQ && long_records) atomicAdd(&sm.misc[5], long_records);
     __syncthreads();
     MHX_STAMP(); // 3: good-base map
 
@@ -238,6 +239,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
         if (sm.misc[3]) atomicAdd(&stats[kStatKmers], (unsigned long long)sm.misc[3]);
         if (sm.misc[4]) atomicAdd(&stats[kStatInserts], (unsigned long long)sm.misc[4]);
         if (FASTQ && tile_total) atomicAdd(&stats[kStatLines], (unsigned long long)tile_total);
+        if (FASTQ && sm.misc[5]) atomicAdd(&stats[kStatRecords], (unsigned long long)sm.misc[5]);
     }
 }
 

@@ -37,6 +37,11 @@ struct TileSmem {
     uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
 };
 
+// The newline bit map of the tile lives in the (not yet used) work-list area between the classify
+// and the good-map phases: 1 bit per byte, kTileBytes/32 + 2 words.
+static_assert(sizeof(uint16_t) * kGroupsPerTile >= sizeof(uint32_t) * (kTileBytes / 32 + 2), "nl map must fit the list area");
+MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return reinterpret_cast<uint32_t *>(sm.list); }
+
 // per-thread state carried between phases (registers on the GPU)
 struct ThreadState {
     uint32_t nl[kWordsPerThread], acgt[kWordsPerThread]; // masks of this thread's 32-byte words
@@ -122,12 +127,23 @@ MHX_HD uint32_t inrange_mask(uint64_t A, uint64_t begin, uint64_t end)
     return m;
 }
 
+// Counts the records mash counts: those whose sequence line holds at least k bytes (feeds the
+// "[N seqs]" comment of the .msh).  A sequence line starts right after the newline that ends a
+// header; it is long enough iff none of its first k bytes is a newline and they all lie in the span.
+struct LineLenCheck {
+    const uint32_t *nlmap; // one newline bit per tile byte (+ the 64 halo bytes), span-masked
+    uint64_t tile_off;     // absolute offset of tile byte 0
+    uint64_t end;          // span end
+    uint32_t k;
+    uint32_t count;
+};
+
 // Bytes of lines whose index is 1 (mod 4), newline bytes excluded.  `line` is the line
 // index at the first byte of the word.  Also verifies the 4-line layout: the line after a
 // newline must start with '@' (index 0 mod 4) or '+' (index 2 mod 4).  tile_bytes/word_off
 // locate the word inside the staged tile for that look-ahead (nullptr: skip the check).
 MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_bytes, uint32_t word_off,
-                             uint32_t check_limit, bool &bad_format)
+                             uint32_t check_limit, bool &bad_format, LineLenCheck *lc = nullptr)
 {
     uint32_t m = 0, cur = 0xFFFFFFFFu;
     while (nl) {
@@ -141,6 +157,12 @@ MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_byt
             if (pos < check_limit) {
                 const uint8_t c = tile_bytes[pos];
                 if (((line & 3u) == 0u && c != '@') || ((line & 3u) == 2u && c != '+')) bad_format = true;
+            }
+            if (lc && (line & 3u) == 1u) { // a sequence line starts at tile byte `pos`
+                const uint32_t wq = pos >> 5, sh = pos & 31u;
+                const uint32_t window = funnel_bits(lc->nlmap[wq + 1], lc->nlmap[wq], sh); // newline bits of bytes pos..pos+31
+                const uint32_t first_k = lc->k >= 32 ? 0xFFFFFFFFu : ((1u << lc->k) - 1u);
+                if ((window & first_k) == 0 && lc->tile_off + pos + lc->k <= lc->end) ++lc->count;
             }
         }
         nl &= nl - 1u;
@@ -269,6 +291,7 @@ MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile
         st.nl[w] = nl & in;
         st.acgt[w] = ac & in;
         total += (uint32_t)__builtin_popcount(st.nl[w]);
+        if (FASTQ) tile_nlmap(sm)[tid * kWordsPerThread + w] = st.nl[w];
     }
     st.nlcount = total;
     if (tid == 0) {
@@ -280,23 +303,26 @@ MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile
             const uint32_t in = inrange_mask(tile_off + kTileBytes + 32u * w, begin, end);
             st.hnl[w] = nl & in;
             st.hacgt[w] = ac & in;
+            if (FASTQ) tile_nlmap(sm)[kTileBytes / 32 + w] = st.hnl[w];
         }
     }
 }
 
 
 // P2c: good-base bits -> sm.good
+// returns the number of records of this thread's bytes whose sequence line holds >= k bytes
 template <bool FASTQ>
-MHX_HD void phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t line_base, uint32_t excl,
-                       uint32_t tile_total, uint32_t check_limit, bool &bad_format)
+MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t line_base, uint32_t excl,
+                           uint32_t tile_total, uint32_t check_limit, bool &bad_format, uint64_t tile_off, uint64_t end, uint32_t k)
 {
     const uint8_t *tb = reinterpret_cast<const uint8_t *>(sm.bytes);
+    LineLenCheck lc{tile_nlmap(sm), tile_off, end, k, 0u};
     uint32_t line = line_base + excl;
 #pragma unroll
     for (int w = 0; w < kWordsPerThread; ++w) {
         uint32_t g = st.acgt[w];
         if (FASTQ) {
-            g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format);
+            g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format, &lc);
             line += (uint32_t)__builtin_popcount(st.nl[w]);
         }
         sm.good[tid * kWordsPerThread + w] = g;
@@ -316,6 +342,7 @@ MHX_HD void phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t li
         sm.good[kTileBytes / 32 + 2] = 0;
         sm.good[kTileBytes / 32 + 3] = 0;
     }
+    return lc.count;
 }
 
 // P3: valid k-mer starts of this thread's positions -> sm.valid, #items -> sm.cnt

@@ -93,6 +93,7 @@ def load() -> ctypes.CDLL:
     L.mhx_sketcher_sync.argtypes = [c.c_void_p]
     L.mhx_sketcher_finish.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, u32p]
     L.mhx_sketcher_stats.argtypes = [c.c_void_p, c.c_void_p]
+    L.mhx_sketcher_record_count.argtypes = [c.c_void_p, c.c_void_p]
     L.mhx_set_profiling.argtypes = [c.c_int]
     L.mhx_stream.restype = c.c_void_p
     L.mhx_sketcher_threshold.argtypes = [c.c_void_p, u64p]
@@ -265,6 +266,12 @@ class Sketcher:
         return {"kmers": int(raw[0]), "inserts": int(raw[1]), "lines": int(raw[2]), "flags": int(raw[3]),
                 "occupied": int(raw[4]), "hash_ms": float(raw[5:6].view(np.float64)[0]), "launches": int(raw[6]),
                 "threshold": int(raw[7])}
+
+    def record_count(self) -> int:
+        """FASTQ records pushed so far whose sequence line holds >= k bytes (mash's sequence count)."""
+        n = ctypes.c_uint64(0)
+        _check(load().mhx_sketcher_record_count(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def threshold(self) -> int:
         v = ctypes.c_uint64(0)

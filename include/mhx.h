@@ -101,6 +101,9 @@ int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, ui
  * [3] device flags, [4] occupied table slots, [5] hash-kernel ms (profiling on), [6] launches,
  * [7] threshold */
 int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8);
+/* FASTQ4 pushes so far: records whose sequence line holds >= k bytes -- the sequences `mash sketch`
+ * counts (it skips shorter ones) and reports as "[N seqs]" in the .msh comment */
+int mhx_sketcher_record_count(mhx_sketcher *sk, uint64_t *records);
 int mhx_sketcher_debug_stamps(mhx_sketcher *sk, uint64_t *out8); /* per-phase cycle sums of a -DMHX_STAMPS diagnostic build */
 int mhx_set_profiling(int on);   /* time hash-kernel launches with HIP events on the engine stream */
 void *mhx_stream(void);          /* the engine's hipStream_t */

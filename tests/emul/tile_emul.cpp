@@ -39,7 +39,7 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         bool bad = false;
         const uint64_t span_left = end > tile_off ? end - tile_off : 0;
         const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
-        for (int t = 0; t < kBlock; ++t) phase_good<FASTQ>(sm, t, st[t], line_base, excl[t], tile_total, check_limit, bad);
+        for (int t = 0; t < kBlock; ++t) stats[kStatRecords] += phase_good<FASTQ>(sm, t, st[t], line_base, excl[t], tile_total, check_limit, bad, tile_off, end, (uint32_t)K);
         if (bad) stats[kStatFlags] |= kFlagBadFastq;
         uint32_t ex2[kBlock], run = 0;
         for (int t = 0; t < kBlock; ++t) { uint32_t items = 0; stats[kStatKmers] += phase_runs<K>(sm, t, items); ex2[t] = run; run += items; }

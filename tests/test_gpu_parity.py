@@ -426,12 +426,17 @@ def test_many_pushes_far_beyond_the_expected_size_stay_exact():
         assert st["flags"] == 0
 
 
-def test_streaming_ingest_fast_plain_file_path(tmp_path, monkeypatch):
-    """Large uncompressed FASTQ files take the vectorised-newline-count path (record cut by counting
-    back from the chunk end); forced here on a 100 MB file with a ragged tail."""
-    monkeypatch.setenv("MHX_INGEST_FAST", "1")
+@pytest.mark.parametrize("bulk", [True, False])
+def test_plain_fastq_file_bulk_and_chunked_ingest(tmp_path, monkeypatch, bulk):
+    """Uncompressed FASTQ: the whole file goes to one device buffer (parallel pread -> pinned ring ->
+    H2D) and is parsed there in one push; MHX_NO_BULK=1 sends it through the 32 MiB chunk queue
+    instead.  100 MB file that starts with records shorter than k (mash neither counts nor names
+    them) and ends without a final newline."""
+    if not bulk:
+        monkeypatch.setenv("MHX_NO_BULK", "1")
     genome = synth.make_genome(300_000, seed=18)
-    a = synth.make_fastq(genome, 330_000, 150, seed=19, device="cpu").numpy().tobytes()     # 104 MB -> 4 chunks
+    a = b"@tiny1 x\nACGT\n+\nIIII\n@tiny2\n\n+\n\n"
+    a += synth.make_fastq(genome, 330_000, 150, seed=19, device="cpu").numpy().tobytes()     # 104 MB -> 4 chunks
     a += b"@tail\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII"            # no final newline
     p = tmp_path / "big.fq"
     p.write_bytes(a)
@@ -441,7 +446,7 @@ def test_streaming_ingest_fast_plain_file_path(tmp_path, monkeypatch):
     want, _ = ref.finish()
     got = mo.read_msh(tmp_path / "b.msh").references[0]
     assert np.array_equal(got.hashes, want)
-    assert got.comment == "[330001 seqs] r00000000  [...]"
+    assert got.comment == ref.comment() == "[330001 seqs] r00000000  [...]"
 
 
 @pytest.mark.parametrize("k", [16, 21, 27, 32])

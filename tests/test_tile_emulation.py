@@ -195,3 +195,19 @@ def test_fastq4_empty_reads_and_single_record(emul):
     one = b"@only\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40
     got, stats = run_emul(emul, one, 21, fmt=1, lead=9)
     assert np.array_equal(got, oracle_hashes([b"ACGT" * 10], 21))
+
+
+@pytest.mark.parametrize("k", [21, 27, 32, 5])
+def test_fastq_counts_records_with_sequence_of_at_least_k_bytes(emul, k):
+    """mash counts a sequence only when it is at least k long (the "[N seqs]" comment); the device
+    counts them at the header-ending newlines, across word, thread and tile borders."""
+    rng = np.random.default_rng(500 + k)
+    reads = random_reads(rng, 700, 0, 90, p_n=0.3)
+    data = fastq_bytes(rng, reads)
+    assert len(data) > 2 * 16384
+    got, stats = run_emul(emul, data, k, fmt=1, lead=13)
+    assert int(stats[3]) == 0
+    assert int(stats[7]) == sum(1 for r in reads if len(r) >= k)
+    # last record without its final newline
+    got, stats = run_emul(emul, data[:-1], k, fmt=1)
+    assert int(stats[7]) == sum(1 for r in reads if len(r) >= k)
