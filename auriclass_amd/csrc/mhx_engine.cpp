@@ -338,7 +338,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     }
     a.tile_state = sk->d_tile_state;
     TableArgs ta = table_args(sk);
-    if (sk->nslots >= (1ull << 23) && !getenv("MHX_EXACT_TIGHTEN")) ta.sample = 8; // big tables: sampled passes between chunks
+    if (sk->nslots >= (1ull << 23) && !getenv("MHX_EXACT_TIGHTEN")) ta.sample = 8; // big tables: sampled passes between chunks (finish() counts exactly)
     uint32_t tile = 0;
     int launch = 0;
     while (tile < ntiles) {

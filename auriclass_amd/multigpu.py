@@ -1,15 +1,17 @@
 """Sharded sketching across the GPUs of one node: one process per GPU (torch.distributed,
 backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests), each rank sketches its own
-record-aligned shard, then ONE exchange step merges the partial results:
+record-aligned shard, then ONE collective merges the partial results:
 
-  1. all-gather of the ranks' 8-byte admission thresholds  -> common limit T_min = their minimum
-  2. every rank exports all (hash, count) it saw with hash <= T_min (no multiplicity filter,
-     so counts stay summable) and all-gathers ONE fixed-size slab [n, hashes.., counts..]
-  3. every rank merges: sum counts per hash, keep count >= m, first s ascending.
+  1. every rank exports all (hash, count) it saw with hash <= its own admission threshold T_r
+     (no multiplicity filter, so counts stay summable)
+  2. ONE all-gather of a fixed-size slab per rank: [n, T_r, hashes.., counts..]
+  3. every rank takes T_min = min_r T_r, drops what lies above it, and merges: sum counts per hash,
+     keep count >= m, first s ascending.
 
 Exact for any m: each rank's threshold never drops below the global s-th qualifying hash
-(local counts are lower bounds of global counts), so below T_min every rank has complete
-counts.  The payload is a few thousand 12-byte entries per rank: latency-bound, not link-bound.
+(local counts are lower bounds of global counts), so below T_min every rank's list is complete
+and its counts are exact.  The payload is a few thousand 12-byte entries per rank: latency-bound,
+not link-bound, which is why it is a single collective.
 """
 from __future__ import annotations
 
@@ -37,34 +39,34 @@ def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.nd
                        device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
     """The exchange step. `export(limit)` -> (hashes, counts) of this rank; `merge` = engine.merge_partials.
     Works on any initialised process group; tensors live on `device` (cuda for nccl, cpu for gloo).
-    Two collectives: an all-gather of the 8-byte thresholds, and an all-gather of one fixed-size slab
-    per rank ([n, hashes.., counts..], 4*s + 4096 entries; a second, exact-size round only if a rank
-    holds more)."""
-    world = dist.get_world_size()
-    # 1. common limit = min over ranks (u64 travels as int64 bits)
-    mine = torch.tensor([np.uint64(local_threshold).astype(np.uint64).view(np.int64)], dtype=torch.int64, device=device)
-    t_min = min(int(np.int64(x.item()).view(np.uint64)) for x in _gather(mine))
-    # 2. slabs
-    hashes, counts = export(t_min)
+    One collective: an all-gather of one fixed-size slab per rank ([n, threshold, hashes.., counts..],
+    4*s + 4096 entries; a second, exact-size round only if a rank holds more)."""
+    hashes, counts = export(local_threshold)
     cap = 4 * s + 4096
     n = len(hashes)
 
     def slab(capacity: int) -> torch.Tensor:
-        buf = np.zeros(1 + 2 * capacity, dtype=np.int64)
+        buf = np.zeros(2 + 2 * capacity, dtype=np.int64)
         buf[0] = n
+        buf[1] = np.uint64(local_threshold).astype(np.uint64).view(np.int64)   # u64 travels as int64 bits
         m = min(n, capacity)
-        buf[1:1 + m] = hashes[:m].view(np.int64)
-        buf[1 + capacity:1 + capacity + m] = counts[:m]
+        buf[2:2 + m] = hashes[:m].view(np.int64)
+        buf[2 + capacity:2 + capacity + m] = counts[:m]
         return torch.from_numpy(buf).to(device)
 
     got = [x.cpu().numpy() for x in _gather(slab(cap))]
     sizes = [int(g[0]) for g in got]
-    if max(sizes) > cap:   # rare: a rank saw more distinct hashes below the limit than the fixed slab holds
+    if max(sizes) > cap:   # rare: a rank saw more distinct hashes below its threshold than the fixed slab holds
         cap = max(sizes)
         got = [x.cpu().numpy() for x in _gather(slab(cap))]
-    # 3. merge
-    all_h = [g[1:1 + sizes[r]].view(np.uint64) for r, g in enumerate(got)]
-    all_c = [g[1 + cap:1 + cap + sizes[r]].astype(np.uint32) for r, g in enumerate(got)]
+    t_min = min(int(g[1:2].view(np.uint64)[0]) for g in got)
+    all_h, all_c = [], []
+    for r, g in enumerate(got):
+        h = g[2:2 + sizes[r]].view(np.uint64)
+        c = g[2 + cap:2 + cap + sizes[r]].astype(np.uint32)
+        keep = h <= np.uint64(t_min)
+        all_h.append(h[keep])
+        all_c.append(c[keep])
     return merge(np.concatenate(all_h), np.concatenate(all_c), s, min_mult)
 
 

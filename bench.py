@@ -208,7 +208,7 @@ def main() -> None:
                     "kmers_per_s": round(st["kmers"] / (kernel_ms / 1e3) / 1e9, 3), "kmers_unit": "G k-mers/s"}
 
         # ---- CPU baseline + parity on a bounded sample of the same workload -------------------
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is an N=1 figure; at N>1 every rank's host cores are busy
             n_s = min(args.cpu_sample_reads, args.reads)
             rb = synth.record_bytes(args.read_len)
             sample = fq[: n_s * rb].cpu().numpy()
