@@ -319,9 +319,14 @@ __global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
     uint32_t before = 0;
     for (int i = 0; i < t; ++i) before += part[i];
     __syncthreads();
-    // sampled pass: counts are 1/sample of the truth; ask for twice the sketch size so that the
-    // sampling error cannot push T below the true s-th qualifying hash (finish() re-checks exactly)
-    const uint32_t s = a.sample > 1 ? (2 * a.sketch_size + a.sample - 1) / a.sample + 16 : a.sketch_size;
+    // sampled pass: counts are ~Binomial(truth, 1/sample); ask for the expected s/sample plus six
+    // standard deviations (+16 for small s) so that the sampling error cannot push T below the true
+    // s-th qualifying hash (~1e-9 per pass; finish() re-checks exactly and refuses otherwise)
+    uint32_t s = a.sketch_size;
+    if (a.sample > 1) {
+        const float mean = (float)a.sketch_size / (float)a.sample;
+        s = (uint32_t)(mean + 6.0f * sqrtf(mean)) + 16u;
+    }
     if (before < s && before + c0 >= s) atomicMin(&cut, (uint32_t)(2 * t));
     else if (before + c0 < s && before + c0 + c1 >= s) atomicMin(&cut, (uint32_t)(2 * t + 1));
     a.hist[2 * t] = 0;
