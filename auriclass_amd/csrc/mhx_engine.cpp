@@ -811,12 +811,15 @@ static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t
 namespace {
 constexpr size_t kIngestChunk = 32u << 20;
 
+// One record-aligned piece of an inflated FASTQ.  The buffer keeps GzInflater::kWindow bytes of room in
+// front of the data: the previous 32 KiB of the stream, which DEFLATE matches may still refer to.
 struct IngestChunk {
-    std::unique_ptr<uint8_t[]> buf; // kIngestChunk bytes, not zero-filled
+    std::unique_ptr<uint8_t[]> buf; // kWindow + kIngestChunk + slack bytes, not zero-filled
     size_t size = 0;
     int file = 0;
     bool first_of_file = false;
-    uint8_t *data() { return buf.get(); }
+    uint8_t *data() { return buf.get() + GzInflater::kWindow; }
+    static size_t alloc_bytes() { return GzInflater::kWindow + kIngestChunk + GzInflater::kOvershoot + 64; }
 };
 
 class ChunkQueue {
@@ -874,44 +877,75 @@ static size_t count_newlines(const uint8_t *p, size_t n)
     return c;
 }
 
+static bool read_whole_file(const char *path, std::vector<uint8_t> &out, size_t pad)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0) { fclose(f); return false; }
+    out.assign((size_t)sb.st_size + pad, 0);
+    const size_t got = fread(out.data(), 1, (size_t)sb.st_size, f);
+    fclose(f);
+    return got == (size_t)sb.st_size;
+}
+
+// Producer of one input file: inflates it (own DEFLATE decoder on the whole compressed file in memory;
+// MHX_ZLIB_INFLATE=1 selects zlib's gzread instead; an uncompressed file is simply read) and cuts the
+// stream into record-aligned chunks.
 void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *st)
 {
     const bool gz = is_gzip_file(path);
+    const bool own = gz && !getenv("MHX_ZLIB_INFLATE");
     gzFile g = nullptr;
     FILE *plain = nullptr;
-    if (gz) {
+    std::vector<uint8_t> zbytes;
+    GzInflater inf;
+    if (own) {
+        if (!read_whole_file(path, zbytes, 16)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
+        inf.set_input(zbytes.data(), zbytes.size() - 16);
+    } else if (gz) {
         g = gzopen(path, "rb");
         if (g) gzbuffer(g, 1 << 20);
     } else {
         plain = fopen(path, "rb");
     }
-    if (!g && !plain) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
+    if (!own && !g && !plain) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
     auto close_all = [&]() { if (g) gzclose(g); if (plain) fclose(plain); };
-    std::vector<uint8_t> carry;
+    std::vector<uint8_t> tail; // [history in front of the carry][carry]: the end of the previous chunk's stream
+    size_t carry_len = 0;
+    uint64_t produced = 0;     // inflated bytes so far (bounds how far back a match may reach)
     bool first = true;
     uint64_t lines_before = 0; // newlines in everything already emitted
     for (;;) {
         IngestChunk c;
         c.file = file;
         c.first_of_file = first;
-        c.buf.reset(new uint8_t[kIngestChunk]);
+        c.buf.reset(new uint8_t[IngestChunk::alloc_bytes()]);
         uint8_t *d = c.data();
-        size_t n = carry.size();
-        if (n) memcpy(d, carry.data(), n);
-        carry.clear();
+        if (!tail.empty()) memcpy(d + carry_len - tail.size(), tail.data(), tail.size());
+        size_t n = carry_len;
         bool eof = false;
         while (n < kIngestChunk) {
             long got;
-            if (gz) got = gzread(g, d + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
-            else { got = (long)fread(d + n, 1, kIngestChunk - n, plain); if (got == 0 && ferror(plain)) got = -1; }
+            if (own) {
+                const uint64_t hist = produced < GzInflater::kWindow ? produced : GzInflater::kWindow;
+                const size_t r = inf.inflate(d + n, kIngestChunk - n, d + n - hist);
+                if (r == (size_t)-1) got = -1;
+                else { got = (long)r; produced += r; if (inf.done()) { n += r; eof = true; break; } }
+            } else if (gz) {
+                got = gzread(g, d + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
+            } else {
+                got = (long)fread(d + n, 1, kIngestChunk - n, plain);
+                if (got == 0 && ferror(plain)) got = -1;
+            }
             if (got < 0) { st->error = std::string("ERROR: reading ") + path + " failed"; close_all(); q->producer_done(); return; }
             if (got == 0) { eof = true; break; }
             n += (size_t)got;
         }
         if (first && n && d[0] != '@') { st->not_fastq4 = true; close_all(); q->producer_done(); return; }
-        // cut after the last newline that completes a record (line count multiple of 4)
-        // (a vectorised newline count, then a short walk back over the unfinished last record;
-        // the records themselves are parsed and counted on the device)
+        // cut after the last newline that completes a record (line count multiple of 4): a vectorised
+        // newline count, then a short walk back over the unfinished last record; the records themselves
+        // are parsed and counted on the device
         size_t cut = 0;
         uint64_t lines = lines_before + count_newlines(d, n), lines_at_cut = lines_before;
         {
@@ -930,7 +964,14 @@ void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *s
             st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
         }
         if (st->not_fastq4) { close_all(); q->producer_done(); return; }
-        if (cut < n) carry.assign(d + cut, d + n);
+        carry_len = n - cut;
+        if (!eof) {
+            // the next chunk starts with the carry; in front of it goes what is left of the 32 KiB window
+            const size_t want = carry_len >= GzInflater::kWindow ? carry_len : GzInflater::kWindow;
+            const size_t have = (size_t)std::min<uint64_t>(own ? produced : 0, want); // zlib keeps its own window
+            const size_t keep = have > carry_len ? have : carry_len;
+            tail.assign(d + n - keep, d + n);
+        }
         c.size = cut;
         st->bytes += cut;
         st->lines = lines_at_cut;
@@ -1092,7 +1133,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     }
     // 2. compressed files: one inflate thread per file, 32 MiB record-aligned chunks
     uint8_t *d_slot = nullptr;
-    if (!rc && !fallback && !queued.empty() && hipMalloc((void **)&d_slot, kIngestChunk + 64) != hipSuccess)
+    if (!rc && !fallback && !queued.empty() && hipMalloc((void **)&d_slot, kIngestChunk + GzInflater::kOvershoot + 64) != hipSuccess)
         rc = fail(MHX_E_HIP, "hipMalloc failed for the ingest slot");
     std::vector<FileIngestState> st(n_paths);
     if (!rc && !fallback && !queued.empty()) {

@@ -46,6 +46,31 @@ int parse_fastx(const uint8_t *buf, size_t n, int k, ParsedRecords &out);
 bool looks_like_fastq4(const uint8_t *buf, size_t n);
 void first_header(const uint8_t *buf, size_t n, std::string &name, std::string &comment);
 
+// ---- gzip / DEFLATE decoder of the FASTQ ingest (mhx_inflate.cpp) ---------------------------
+class GzInflater {
+  public:
+    static constexpr size_t kWindow = 32768;  // history a match may reach back into
+    static constexpr size_t kOvershoot = 320; // inflate() may write this far past its limit
+    GzInflater();
+    ~GzInflater();
+    GzInflater(const GzInflater &) = delete;
+    GzInflater &operator=(const GzInflater &) = delete;
+    // the compressed file (all members); 16 readable bytes must follow data[n - 1]
+    void set_input(const uint8_t *data, size_t n);
+    void set_verify_crc(bool on);
+    // Produces output at `out` until `limit` bytes are reached (it may run over by < kOvershoot), the
+    // input is exhausted or an error occurs; call again to continue.  [window_start, out) must hold the
+    // previous output (up to 32 KiB of it).  Returns the bytes produced or (size_t)-1.
+    size_t inflate(uint8_t *out, size_t limit, const uint8_t *window_start);
+    bool done() const;
+    const std::string &error() const;
+
+  private:
+    struct Impl;
+    Impl *impl_;
+};
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n);
+
 // ---- statistics / text (mhx_text.cpp) ---------------------------------------------------
 double binomial_cdf(uint64_t x, double p, uint64_t n);        // P[X <= x]
 double binomial_sf_ge(uint64_t x, double p, uint64_t n);      // P[X >= x]

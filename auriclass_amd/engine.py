@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
     L.mhx_p_value.restype = c.c_double
     L.mhx_msh_write.argtypes = [c.c_char_p, c.c_int, c.c_uint32, c.c_uint32, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                 u64p, c.POINTER(u64p), u32p]
+    L.mhx_gunzip_buffer.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t)]
     _lib = L
     return L
 
@@ -290,6 +291,20 @@ class Sketcher:
                 continue
             _check(rc)
             return hashes[:n.value].copy(), counts[:n.value].copy()
+
+
+def gunzip(data: bytes) -> bytes:
+    """Inflate an in-memory .gz (all members) with the ingest's own DEFLATE decoder (host code, no GPU)."""
+    L = load()
+    need = ctypes.c_size_t(0)
+    rc = L.mhx_gunzip_buffer(data, len(data), None, 0, ctypes.byref(need))
+    if rc:
+        raise EngineError(rc, L.mhx_last_error().decode())
+    out = ctypes.create_string_buffer(max(1, need.value))
+    rc = L.mhx_gunzip_buffer(data, len(data), out, need.value, ctypes.byref(need))
+    if rc:
+        raise EngineError(rc, L.mhx_last_error().decode())
+    return out.raw[:need.value]
 
 
 def set_profiling(on: bool) -> None:

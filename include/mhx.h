@@ -134,6 +134,11 @@ int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_refs, const ch
                   const char *const *comments, const uint64_t *lengths, const uint64_t *const *hashes,
                   const uint32_t *n_hashes);
 
+/* gunzip of an in-memory .gz (all members) with the decoder the FASTQ ingest uses in place of zlib
+ * (kseq's gzread inside `mash sketch`, auriclass/classes.py:588).  out == NULL or cap too small:
+ * *out_n still receives the inflated size (MHX_E_CAPACITY in the second case). */
+int mhx_gunzip_buffer(const void *gz, size_t n, void *out, size_t cap, size_t *out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,10 +322,16 @@ def test_dist_more_than_32_refs_and_k16_32bit_hashes():
     _check_all_pairs(qrys, refs[:24], 16, 800)          # fast path on 32-bit hash values
 
 
-def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
+@pytest.mark.parametrize("inflater", ["own", "zlib"])
+def test_streaming_ingest_many_chunks_two_gz_files(tmp_path, monkeypatch, inflater):
     """Reads mode streams each file through its own inflate thread in 32 MiB record-aligned
-    chunks; two files, several chunks each, the second one without a final newline."""
+    chunks; two files, several chunks each, the second one without a final newline.  The .gz goes
+    through the engine's own DEFLATE decoder (matches reach back across chunk borders) or, with
+    MHX_ZLIB_INFLATE=1, through zlib."""
     import gzip
+
+    if inflater == "zlib":
+        monkeypatch.setenv("MHX_ZLIB_INFLATE", "1")
 
     genome = synth.make_genome(400_000, seed=8)
     a = synth.make_fastq(genome, 230_000, 150, seed=9, device="cpu").numpy().tobytes()       # 72 MB -> 3 chunks
@@ -333,7 +339,7 @@ def test_streaming_ingest_many_chunks_two_gz_files(tmp_path):
     b += b"".join(b"@short%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(7))      # shorter than k: not counted by mash
     b = b[:-1]
     pa, pb = tmp_path / "r1.fq.gz", tmp_path / "r2.fq"
-    with gzip.open(pa, "wb", compresslevel=1) as fh:
+    with gzip.open(pa, "wb", compresslevel=6) as fh:
         fh.write(a)
     pb.write_bytes(b)
     out = tmp_path / "s.msh"

@@ -87,3 +87,75 @@ def test_compute_calls_fail_loudly_without_gpu(lib, tmp_path):
         engine.dist_files(REFDATA / "ref_sketch.msh", REFDATA / "ref_sketch.msh")
     with pytest.raises(engine.EngineError):
         engine.Sketcher(21, 1000)
+
+
+# ---- the ingest's own gzip/DEFLATE decoder against zlib ------------------------------------------
+def _gz(data: bytes, level: int = 6, **kw) -> bytes:
+    import gzip
+    import io
+
+    b = io.BytesIO()
+    with gzip.GzipFile(fileobj=b, mode="wb", compresslevel=level, **kw) as f:
+        f.write(data)
+    return b.getvalue()
+
+
+def _fastq_like(rng, n):
+    from auriclass_amd import synth
+
+    g = synth.make_genome(50_000, seed=3)
+    return synth.make_fastq(g, n, 150, seed=int(rng.integers(1, 1000)), device="cpu").numpy().tobytes()
+
+
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
+def test_gunzip_equals_zlib_on_fastq_text_and_binary(lib, level):
+    rng = np.random.default_rng(level)
+    cases = [b"", b"A", b"ACGT" * 70000, bytes(rng.integers(0, 256, 300_000, dtype=np.uint8)),   # empty, tiny, long runs, incompressible
+             _fastq_like(rng, 20_000),                                                                # 6.3 MB: many dynamic blocks
+             bytes(rng.choice(np.frombuffer(b"ACGTN\n", np.uint8), 1_500_000))]
+    for data in cases:
+        assert engine.gunzip(_gz(data, level)) == data
+
+
+def test_gunzip_block_types_members_and_header_fields(lib):
+    import zlib
+
+    rng = np.random.default_rng(77)
+    text = _fastq_like(rng, 3000)
+    # fixed-Huffman blocks (Z_FIXED), stored blocks (level 0), raw long-distance matches (32 KiB window edge)
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strategy)
+        assert engine.gunzip(co.compress(text) + co.flush()) == text
+    far = bytes(rng.integers(0, 256, 32768, dtype=np.uint8))
+    data = far + b"x" * 5 + far + far[:100] * 3
+    assert engine.gunzip(_gz(data, 9)) == data
+    # several members back to back (bgzip-style), with FNAME / mtime header fields, then trailing garbage
+    parts = [text[:100_000], b"", text[100_000:250_000], text[250_000:]]
+    blob = b"".join(_gz(p, 5, filename="reads.fq", mtime=12345) for p in parts)
+    assert engine.gunzip(blob) == b"".join(parts)
+    assert engine.gunzip(blob + b"\0" * 100) == b"".join(parts)
+    # sync-flushed stream: empty stored blocks in the middle
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    z = b"".join(co.compress(text[i:i + 50_000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(text), 50_000)) + co.flush()
+    assert engine.gunzip(z) == text
+
+
+def test_gunzip_rejects_corrupt_streams(lib):
+    rng = np.random.default_rng(5)
+    text = _fastq_like(rng, 2000)
+    z = bytearray(_gz(text, 6))
+    bad = bytes(z[:-8]) + bytes([z[-8] ^ 1]) + bytes(z[-7:])           # wrong CRC
+    with pytest.raises(engine.EngineError):
+        engine.gunzip(bad)
+    with pytest.raises(engine.EngineError):
+        engine.gunzip(bytes(z[: len(z) // 2]))                          # truncated
+    flipped = 0
+    for pos in rng.integers(20, len(z) - 9, 40):                        # random bit flips: error or (rarely) CRC catches it
+        y = bytearray(z)
+        y[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = engine.gunzip(bytes(y))
+            assert out == text      # a flip that does not change the output (e.g. in a header field) is fine
+        except engine.EngineError:
+            flipped += 1
+    assert flipped >= 30
