@@ -3,14 +3,21 @@
 // Mirrors what `mash sketch` does with zlib + kseq.h before its hot loop (Mash 2.x
 // Sketch.cpp sketchFile); the files are the ones AuriClass passes through unchanged at
 // /root/reference/auriclass/classes.py:588 and :705.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 #include "mhx_internal.h"
 
 namespace mhx {
 
-int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
+// whole file -> bytes; a gzip file (any number of members) is inflated with the engine's own decoder
+// (mhx_inflate.cpp; MHX_ZLIB_INFLATE=1: zlib's gzread, which is also what handles non-regular inputs)
+static int read_all_zlib(const char *path, std::vector<uint8_t> &out)
 {
     gzFile g = gzopen(path, "rb"); // transparent for uncompressed files, like mash
     if (!g) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
@@ -28,6 +35,39 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
         n += (size_t)got;
     }
     gzclose(g);
+    out.resize(n);
+    return MHX_OK;
+}
+
+int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
+{
+    struct stat sb;
+    if (getenv("MHX_ZLIB_INFLATE") || stat(path, &sb) != 0 || !S_ISREG(sb.st_mode)) return read_all_zlib(path, out);
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
+    std::vector<uint8_t> raw((size_t)sb.st_size + 16, 0);
+    const size_t got = fread(raw.data(), 1, (size_t)sb.st_size, f);
+    fclose(f);
+    if (got != (size_t)sb.st_size) return fail(MHX_E_IO, "ERROR: reading %s failed", path);
+    if (got < 18 || raw[0] != 0x1f || raw[1] != 0x8b) { // not gzip: the bytes as they are
+        raw.resize(got);
+        out.swap(raw);
+        return MHX_OK;
+    }
+    GzInflater inf;
+    inf.set_input(raw.data(), got);
+    // size hint: ISIZE of the last member
+    const size_t hint = (size_t)raw[got - 4] | ((size_t)raw[got - 3] << 8) | ((size_t)raw[got - 2] << 16) | ((size_t)raw[got - 1] << 24);
+    const size_t slack = GzInflater::kOvershoot + 16;
+    out.assign(std::max<size_t>(hint, 1u << 16) + slack, 0);
+    size_t n = 0;
+    for (;;) {
+        const size_t r = inf.inflate(out.data() + n, out.size() - slack - n, out.data());
+        if (r == (size_t)-1) return fail(MHX_E_IO, "ERROR: reading %s failed (%s)", path, inf.error().c_str());
+        n += r;
+        if (inf.done()) break;
+        if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2); // more members than the hint covered
+    }
     out.resize(n);
     return MHX_OK;
 }
