@@ -505,7 +505,7 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
 {
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemsetAsync(sk->d_out_n, 0, sizeof(uint32_t), g.stream));
-        HIPCHK(launch_extract(table_args(sk), limit, min_count, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, g.stream));
+        HIPCHK(launch_extract(table_args(sk), limit, min_count, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, nullptr, nullptr, g.stream));
         uint32_t n = 0;
         HIPCHK(hipMemcpyAsync(&n, sk->d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -612,6 +612,26 @@ static int mhx_sketcher_export_impl(mhx_sketcher *sk, uint64_t limit, uint64_t *
         memcpy(hashes, keys.data(), keys.size() * sizeof(uint64_t));
         memcpy(counts, cnts.data(), cnts.size() * sizeof(uint32_t));
     }
+    return MHX_OK;
+}
+
+// Multi-GPU fast path: the shard's partial result as ONE device-resident slab of int64 words
+//   [0] n entries (may exceed cap: then only cap are present)   [1] admission threshold T
+//   [2] device flags   [3 .. 3+cap) hashes   [3+cap ..) counts, two u32 per word
+// holding every (hash, count) with hash <= T (T read on the device), unsorted.  Everything is enqueued on the engine stream
+// and the stream is synchronised once, so the slab can go straight into an all-gather; nothing
+// crosses PCIe here.
+extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t cap)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !d_slab || cap == 0 || (cap & 1)) return fail(MHX_E_ARG, "export_slab: null argument or odd capacity");
+    uint64_t *w = (uint64_t *)d_slab;
+    HIPCHK(hipMemsetAsync(w, 0, 3 * sizeof(uint64_t), g.stream));
+    HIPCHK(hipMemcpyAsync(w + 1, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+    HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
 }
 

@@ -361,8 +361,15 @@ hipError_t launch_tighten(const TableArgs &a, hipStream_t st)
 
 __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, uint64_t limit, uint32_t min_count,
                                                             uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
-                                                            uint32_t *out_n)
+                                                            uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev)
 {
+    if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
+    // optional: OR of the replicated device flags, so that a caller that never reads the stats block
+    // (the multi-GPU slab export) still learns about a full table or a malformed FASTQ
+    if (flags_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
+        const uint64_t f = a.stats[threadIdx.x * kStatCount + kStatFlags];
+        if (f) atomicOr(reinterpret_cast<unsigned long long *>(flags_out), (unsigned long long)f);
+    }
     // Qualifying entries are sparse (about one per few hundred slots), so they are collected per
     // workgroup in LDS and appended to the output with ONE global atomic per flush instead of one
     // per entry (a single counter word serialises at ~10 ns per atomic).
@@ -404,12 +411,12 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
 }
 
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
-                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, hipStream_t st)
+                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev, hipStream_t st)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
-                       out_cnts, cap, out_n);
+                       out_cnts, cap, out_n, flags_out, limit_dev);
     return hipGetLastError();
 }
 

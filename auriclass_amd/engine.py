@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
     L.mhx_p_value.restype = c.c_double
     L.mhx_msh_write.argtypes = [c.c_char_p, c.c_int, c.c_uint32, c.c_uint32, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                 u64p, c.POINTER(u64p), u32p]
+    L.mhx_sketcher_export_slab.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32]
     L.mhx_gunzip_buffer.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t)]
     _lib = L
     return L
@@ -278,6 +279,11 @@ class Sketcher:
         v = ctypes.c_uint64(0)
         _check(load().mhx_sketcher_threshold(self._h, ctypes.byref(v)))
         return v.value
+
+    def export_slab(self, device_ptr: int, cap: int) -> None:
+        """Partial result as one device-resident int64 slab [n, T, flags, hashes[cap], counts (u32 pairs)];
+        `device_ptr` must hold 3 + cap + cap // 2 int64 words (see include/mhx.h)."""
+        _check(load().mhx_sketcher_export_slab(self._h, ctypes.c_void_p(device_ptr), cap))
 
     def export(self, limit: int) -> Tuple[np.ndarray, np.ndarray]:
         cap = 1 << 16

@@ -28,10 +28,18 @@ def _to_i64(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(a.astype(np.uint64).view(np.int64).copy())
 
 
-def _gather(t: torch.Tensor) -> List[torch.Tensor]:
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return out
+def _gather(t: torch.Tensor) -> List[np.ndarray]:
+    """All-gather of equally sized 1-D tensors; returns one host array per rank (ONE device-to-host copy)."""
+    world = dist.get_world_size()
+    flat = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(flat, t)
+    except (RuntimeError, NotImplementedError, AttributeError):   # backend without the flat form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        flat = torch.cat(parts)
+    host = flat.cpu().numpy()
+    return [host[r * t.numel():(r + 1) * t.numel()] for r in range(world)]
 
 
 def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.ndarray, np.ndarray]], s: int, min_mult: int,
@@ -54,16 +62,46 @@ def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.nd
         buf[2 + capacity:2 + capacity + m] = counts[:m]
         return torch.from_numpy(buf).to(device)
 
-    got = [x.cpu().numpy() for x in _gather(slab(cap))]
+    got = _gather(slab(cap))
     sizes = [int(g[0]) for g in got]
     if max(sizes) > cap:   # rare: a rank saw more distinct hashes below its threshold than the fixed slab holds
         cap = max(sizes)
-        got = [x.cpu().numpy() for x in _gather(slab(cap))]
+        got = _gather(slab(cap))
     t_min = min(int(g[1:2].view(np.uint64)[0]) for g in got)
     all_h, all_c = [], []
     for r, g in enumerate(got):
         h = g[2:2 + sizes[r]].view(np.uint64)
         c = g[2 + cap:2 + cap + sizes[r]].astype(np.uint32)
+        keep = h <= np.uint64(t_min)
+        all_h.append(h[keep])
+        all_c.append(c[keep])
+    return merge(np.concatenate(all_h), np.concatenate(all_c), s, min_mult)
+
+
+def exchange_and_merge_device(sk, s: int, min_mult: int, merge, device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
+    """The same exchange with the partial results staying on the GPU until they have been gathered:
+    `sk.export_slab` writes [n, T_r, flags, hashes.., counts..] into a device tensor (one kernel, no
+    PCIe), the slabs are all-gathered by RCCL, ONE device-to-host copy brings all of them over, and the
+    merge runs on the host as before.  Falls back to exchange_and_merge (on every rank alike, the decision
+    only uses gathered data) when a slab overflowed or a shard never tightened its threshold."""
+    cap = 4 * s + 4096
+    slab = torch.empty(3 + cap + cap // 2, dtype=torch.int64, device=device)
+    sk.export_slab(slab.data_ptr(), cap)
+    got = _gather(slab)
+    sizes = [int(g[0]) for g in got]
+    thresholds = [int(g[1:2].view(np.uint64)[0]) for g in got]
+    flags = 0
+    for g in got:
+        flags |= int(g[2])
+    if flags:
+        raise RuntimeError(f"device flags {flags:#x} raised during sketching (table full / malformed FASTQ)")
+    if max(sizes) > cap or max(thresholds) == U64_MAX:
+        return exchange_and_merge(sk.threshold(), sk.export, s, min_mult, merge, device)
+    t_min = min(thresholds)
+    all_h, all_c = [], []
+    for r, g in enumerate(got):
+        h = g[3:3 + sizes[r]].view(np.uint64)
+        c = g[3 + cap:].view(np.uint32)[:sizes[r]]
         keep = h <= np.uint64(t_min)
         all_h.append(h[keep])
         all_c.append(c[keep])

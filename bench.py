@@ -150,8 +150,9 @@ def main() -> None:
         sk.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
         if not use_dist:
             return sk.finish()
-        t = sk.threshold()
-        return multigpu.exchange_and_merge(t, sk.export, args.s, args.m, engine.merge_partials, comm_dev)
+        if comm_dev.type == "cuda":   # RCCL: the partial results stay on the GPU until they have been gathered
+            return multigpu.exchange_and_merge_device(sk, args.s, args.m, engine.merge_partials, comm_dev)
+        return multigpu.exchange_and_merge(sk.threshold(), sk.export, args.s, args.m, engine.merge_partials, comm_dev)
 
     def barrier():
         torch.cuda.synchronize()

@@ -114,6 +114,12 @@ void *mhx_stream(void);          /* the engine's hipStream_t */
 int mhx_sketcher_threshold(mhx_sketcher *sk, uint64_t *threshold);
 int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint32_t *counts,
                         uint32_t cap, uint32_t *n_out);
+/* Same partial result, left on the device as one slab of int64 words ready for an all-gather:
+ * [0] n (entries found; only min(n, cap) are stored), [1] the shard's threshold, [2] device flags,
+ * [3, 3+cap) hashes, then cap/2 words holding the u32 counts; every entry <= the threshold, unsorted,
+ * no multiplicity filter.  cap must be even.  The hash value 2^64-1 is not representable here: callers
+ * fall back to mhx_sketcher_export when a threshold of 2^64-1 comes back. */
+int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t cap);
 int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s,
                        uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
 

@@ -67,3 +67,50 @@ def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, 
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
         assert np.load(tmp_path / f"c{r}.npy").min() >= m
+
+
+def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from auriclass_amd import engine
+
+    engine.init(0)
+    fq = torch.from_numpy(_input(n_reads)).to("cuda:0")
+    torch.cuda.synchronize()
+    sk = engine.Sketcher(k, s, m, expected_bytes=fq.numel())
+    sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)
+    got_h, got_c = multigpu.exchange_and_merge_device(sk, s, m, engine.merge_partials, torch.device("cuda", 0))
+    ref_h, ref_c = sk.finish()
+    np.save(os.path.join(out_dir, "slab_h.npy"), got_h)
+    np.save(os.path.join(out_dir, "slab_c.npy"), got_c)
+    np.save(os.path.join(out_dir, "fin_h.npy"), ref_h)
+    np.save(os.path.join(out_dir, "fin_c.npy"), ref_c)
+    # a tiny shard never tightens its threshold: every rank takes the host-side exchange instead
+    sk2 = engine.Sketcher(k, s, m, expected_bytes=0)
+    rb = synth.record_bytes(READ_LEN)
+    sk2.push_device(fq.data_ptr(), 5 * rb, engine.FMT_FASTQ4)
+    tiny_h, _ = multigpu.exchange_and_merge_device(sk2, s, m, engine.merge_partials, torch.device("cuda", 0))
+    want_h, _ = sk2.finish()
+    assert np.array_equal(tiny_h, want_h)
+    sk.close()
+    sk2.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,s,m", [(21, 1000, 1), (21, 1000, 3)])
+def test_device_slab_exchange_over_rccl_equals_finish(tmp_path, k, s, m):
+    """The RCCL form of the exchange (partials gathered on the device, one copy to the host) on the
+    one GPU of the box: a single-rank process group, so the all-gather runs through RCCL itself."""
+    from oracle import mash_oracle as mo
+
+    n_reads = 60_000
+    mp.spawn(_nccl_worker, args=(1, _free_port(), k, s, m, n_reads, str(tmp_path)), nprocs=1, join=True)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(_input(n_reads).tobytes())
+    want, want_c = ref.finish()
+    assert np.array_equal(np.load(tmp_path / "slab_h.npy"), want)
+    assert np.array_equal(np.load(tmp_path / "fin_h.npy"), want)
+    assert np.array_equal(np.load(tmp_path / "slab_c.npy"), np.load(tmp_path / "fin_c.npy"))
