@@ -222,8 +222,8 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     }
     sk->t_init = T;
     sk->last_T = T;
+    // t_init lives in the sketcher and is only written here, so the copy may stay in flight
     HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream)); // t_init is a host stack-free member, but keep reset synchronous
     uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
     if (c0 < (256u << 10)) c0 = 256u << 10;
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
@@ -559,32 +559,48 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !hashes || !n_out) return fail(MHX_E_ARG, "null argument");
-    uint64_t T;
+    // One batch on the stream, one synchronisation: final tighten, extract with the threshold read on the
+    // device, then threshold, counters, entry count and the first entries come back together.
+    uint64_t T = 0;
+    uint32_t n = 0;
+    std::vector<uint64_t> hs(kStatReplicas * kStatCount);
+    const uint32_t first = std::min<uint32_t>(sk->out_cap, 2 * sk->s + 4096);
+    std::vector<uint64_t> keys(first);
+    std::vector<uint32_t> cnts(first);
     HIPCHK(launch_tighten(table_args(sk), g.stream));
-    rc = read_threshold(sk, &T);
+    HIPCHK(hipMemsetAsync(sk->d_out_n, 0, sizeof(uint32_t), g.stream));
+    HIPCHK(launch_extract(table_args(sk), 0, sk->m, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, nullptr, sk->d_thresh, g.stream));
+    HIPCHK(hipMemcpyAsync(&T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(hs.data(), sk->d_stats, hs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(&n, sk->d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(keys.data(), sk->d_out_keys, (size_t)first * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(cnts.data(), sk->d_out_cnts, (size_t)first * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    sk->last_T = T;
+    uint64_t flags = 0, maxkey = 0;
+    for (int r = 0; r < kStatReplicas; ++r) { flags |= hs[r * kStatCount + kStatFlags]; maxkey += hs[r * kStatCount + kStatMaxKey]; }
+    rc = check_flags(flags);
     if (rc) return rc;
-    uint64_t st[kStatCount];
-    rc = fetch_stats(sk, st);
-    if (rc) return rc;
-    rc = check_flags(st[kStatFlags]);
-    if (rc) return rc;
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> cnts;
-    rc = extract(sk, T, sk->m, keys, cnts);
-    if (rc) return rc;
-    if (T == ~0ull && st[kStatMaxKey] >= sk->m) { // the one hash value the table cannot hold
+    if (n > first) { // more entries below T than the first copy covered (or than the device buffer holds)
+        rc = extract(sk, T, sk->m, keys, cnts);
+        if (rc) return rc;
+    } else {
+        keys.resize(n);
+        cnts.resize(n);
+    }
+    if (T == ~0ull && maxkey >= sk->m) { // the one hash value the table cannot hold
         keys.push_back(~0ull);
-        cnts.push_back((uint32_t)st[kStatMaxKey]);
+        cnts.push_back((uint32_t)maxkey);
     }
     // exactness: either nothing was ever rejected, or at least s qualifying hashes lie below T
     if (keys.size() < sk->s && sk->t_init != sk->hash_max)
         return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries); recreate the sketcher with a larger table",
                     keys.size(), sk->s);
     sort_pairs(keys, cnts);
-    const uint32_t n = keys.size() < sk->s ? (uint32_t)keys.size() : sk->s;
-    memcpy(hashes, keys.data(), (size_t)n * sizeof(uint64_t));
-    if (counts) memcpy(counts, cnts.data(), (size_t)n * sizeof(uint32_t));
-    *n_out = n;
+    const uint32_t nn = keys.size() < sk->s ? (uint32_t)keys.size() : sk->s;
+    memcpy(hashes, keys.data(), (size_t)nn * sizeof(uint64_t));
+    if (counts) memcpy(counts, cnts.data(), (size_t)nn * sizeof(uint32_t));
+    *n_out = nn;
     return MHX_OK;
 }
 

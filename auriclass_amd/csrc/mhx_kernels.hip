@@ -285,14 +285,23 @@ __global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
     // any fixed subset of blocks is a uniform sample of the entries)
     const uint64_t nblocks256 = a.nslots / 256;
     const uint64_t step = a.sample > 1 ? a.sample : 1;
-    for (uint64_t b = (uint64_t)blockIdx.x * step; b < nblocks256; b += (uint64_t)gridDim.x * step) {
-        const uint64_t i = b * 256 + threadIdx.x;
-        const uint64_t key = a.keys[i];
-        if (key == kEmptyKey) continue;
-        ++occ;
-        if (key <= T && a.cnts[i] >= a.min_mult) {
-            ++solid;
-            atomicAdd(&h[(key << lz) >> (64 - 11)], 1u);
+    // four independent key loads in flight per thread: with one, the pass is a chain of L2/HBM round trips
+    const uint64_t stride = (uint64_t)gridDim.x * step;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * step; b0 < nblocks256; b0 += 4 * stride) {
+        uint64_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t b = b0 + u * stride;
+            key[u] = b < nblocks256 ? a.keys[b * 256 + threadIdx.x] : kEmptyKey;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (key[u] == kEmptyKey) continue;
+            ++occ;
+            if (key[u] <= T && a.cnts[(b0 + u * stride) * 256 + threadIdx.x] >= a.min_mult) {
+                ++solid;
+                atomicAdd(&h[(key[u] << lz) >> (64 - 11)], 1u);
+            }
         }
     }
     if (occ) atomicAdd(&occ_s, occ);
