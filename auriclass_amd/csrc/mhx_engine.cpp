@@ -171,6 +171,10 @@ struct mhx_sketcher {
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
+#ifndef MHX_CHUNK_GROWTH
+#define MHX_CHUNK_GROWTH 16
+#endif
+static constexpr uint64_t kChunkGrowth = MHX_CHUNK_GROWTH; // chunk size ratio between tighten rounds
 
 static TableArgs table_args(mhx_sketcher *sk)
 {
@@ -375,7 +379,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             const uint64_t remaining = total > sk->bytes_pushed ? total - sk->bytes_pushed : (uint64_t)(ntiles - tile) * kTileBytes;
             const long double admit = (long double)remaining * ((long double)T / (long double)sk->hash_max);
             if (admit <= (long double)(sk->nslots / 8)) { sk->settled = true; sk->settled_total = total > sk->bytes_pushed ? total : sk->bytes_pushed; }
-            else sk->next_chunk_bytes *= 4;
+            else sk->next_chunk_bytes *= kChunkGrowth;
         }
     }
     return MHX_OK;
