@@ -69,10 +69,10 @@ MHX_HD uint32_t perm_lut(uint32_t lut, uint32_t sel)
     return o;
 #endif
 }
-// order-preserving 2-bit codes of A,C,G,T (either case folded by the caller): 0,1,2,3
-MHX_HD uint32_t base_codes(uint32_t u) { return ((u >> 1) & 0x03030303u) ^ ((u >> 2) & 0x01010101u); }
-constexpr uint32_t kLutFwd = 0x54474341u;  // code -> 'A','C','G','T'
-constexpr uint32_t kLutComp = 0x41434754u; // code -> complement 'T','G','C','A'
+// 2-bit index of a (case-folded) byte: bits 1..2, which tell A, C, G, T apart (0, 1, 3, 2); any other
+// byte lands on one of the four as well and is exposed by the comparison with the table entry
+MHX_HD uint32_t base_index(uint32_t u) { return (u >> 1) & 0x03030303u; }
+constexpr uint32_t kLutBase = 0x47544341u; // index -> 'A','C','T','G'
 
 // low 32 bits of {hi:lo} >> (8 * byte_shift), byte_shift in 0..3.  On the device this must be
 // the v_alignbyte/v_alignbit instruction itself: written as a C shift-or, LLVM turns the
@@ -111,7 +111,7 @@ template <bool WANT_NL> MHX_HD void classify_word(const uint32_t *p, uint32_t &n
         const uint32_t v = p[d];
         if (WANT_NL) n |= flags_to_nibble(zero_byte_flags(v ^ 0x0A0A0A0Au)) << (4 * d);
         const uint32_t u = v & 0xDFDFDFDFu;
-        const uint32_t asc = perm_lut(kLutFwd, base_codes(u));
+        const uint32_t asc = perm_lut(kLutBase, base_index(u));
         a |= flags_to_nibble(zero_byte_flags(asc ^ u)) << (4 * d);
     }
     nl = n;
