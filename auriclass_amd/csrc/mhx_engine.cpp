@@ -1128,7 +1128,8 @@ static void first_counted_header(const uint8_t *buf, size_t n, int k, std::strin
         const size_t s0 = (size_t)(h_end - buf) + 1;
         const uint8_t *s_end = s0 < n ? (const uint8_t *)memchr(buf + s0, '\n', n - s0) : nullptr;
         const size_t s1 = s_end ? (size_t)(s_end - buf) : n;
-        if (s1 - s0 >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return; }
+        const size_t seq_len = s1 - s0 - ((s1 > s0 && buf[s1 - 1] == '\r') ? 1 : 0); // CRLF files: the CR is not a base
+        if (seq_len >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return; }
         // skip the '+' and quality lines
         size_t q = s1 + 1;
         for (int i = 0; i < 2 && q < n; ++i) {

@@ -162,7 +162,13 @@ MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_byt
                 const uint32_t wq = pos >> 5, sh = pos & 31u;
                 const uint32_t window = funnel_bits(lc->nlmap[wq + 1], lc->nlmap[wq], sh); // newline bits of bytes pos..pos+31
                 const uint32_t first_k = lc->k >= 32 ? 0xFFFFFFFFu : ((1u << lc->k) - 1u);
-                if ((window & first_k) == 0 && lc->tile_off + pos + lc->k <= lc->end) ++lc->count;
+                if ((window & first_k) == 0 && lc->tile_off + pos + lc->k <= lc->end) {
+                    // a '\r' that ends the line is not part of the sequence (kseq drops it): if the k-th byte
+                    // is a CR followed by the newline (or by the end of the stream) the line has k-1 bases
+                    const uint32_t after = pos + lc->k;
+                    const bool ends_here = lc->tile_off + after >= lc->end || ((lc->nlmap[after >> 5] >> (after & 31u)) & 1u);
+                    if (!(tile_bytes[after - 1u] == '\r' && ends_here)) ++lc->count;
+                }
             }
         }
         nl &= nl - 1u;

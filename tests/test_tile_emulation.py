@@ -211,3 +211,21 @@ def test_fastq_counts_records_with_sequence_of_at_least_k_bytes(emul, k):
     # last record without its final newline
     got, stats = run_emul(emul, data[:-1], k, fmt=1)
     assert int(stats[7]) == sum(1 for r in reads if len(r) >= k)
+
+
+@pytest.mark.parametrize("k", [21, 32])
+def test_fastq_with_crlf_line_ends(emul, k):
+    """CRLF files: the CR is a non-base byte (no k-mer crosses it) and does not count towards the
+    sequence length (kseq drops it), so reads of exactly k-1 bases stay uncounted."""
+    rng = np.random.default_rng(900 + k)
+    reads = random_reads(rng, 400, k - 3, k + 3, p_n=0.1)
+    data = fastq_bytes(rng, reads).replace(b"\n", b"\r\n")
+    got, stats = run_emul(emul, data, k, fmt=1, lead=5)
+    ref = mo.Sketcher(k, 1 << 20, 1)
+    ref.add_fastx(data)
+    want, _ = ref.finish()
+    assert int(stats[3]) == 0
+    assert np.array_equal(np.unique(got), want)
+    assert int(stats[7]) == ref.records == sum(1 for r in reads if len(r) >= k)
+    got, stats = run_emul(emul, data[:-1], k, fmt=1)     # ends with a bare CR
+    assert int(stats[7]) == ref.records
