@@ -141,7 +141,8 @@ struct mhx_sketcher {
     bool hash32 = false;
     uint64_t nslots = 0;
     uint64_t hash_max = 0;   // largest representable hash (2^64-1 or 2^32-1)
-    uint64_t t_init = 0;     // initial admission threshold
+    uint64_t t_init = 0;     // initial admission threshold (everything admitted)
+    uint64_t t_write = 0;    // staging word for thresholds the host imposes
     // device
     uint64_t *d_keys = nullptr;
     uint32_t *d_cnts = nullptr;
@@ -168,6 +169,11 @@ struct mhx_sketcher {
     double hash_ms = 0.0;
     uint64_t launches = 0;
     uint64_t last_T = 0;
+    // m > 1 only: until s hashes with count >= m exist below T the table is protected by a bound that
+    // follows the input seen so far (see push_device)
+    bool bounded = false;      // a host-imposed bound has limited T at least once
+    bool established = false;  // the tighten pass has lowered T from solid (count >= m) entries
+    uint64_t occupied = 0;     // table occupancy reported by the last tighten pass
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
@@ -212,24 +218,18 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     HIPCHK(hipMemsetAsync(sk->d_hist, 0, kHistBins * sizeof(uint32_t), g.stream));
     HIPCHK(hipMemsetAsync(sk->d_acc, 0, 2 * sizeof(uint64_t), g.stream));
     HIPCHK(hipMemsetAsync(sk->d_stats, 0, kStatReplicas * kStatCount * sizeof(uint64_t), g.stream));
-    // Admission threshold.  With everything admitted the table must be able to hold every
-    // distinct k-mer of the first chunk; for larger inputs start from the occurrence bound
-    // (at most nslots/4 admissions over the whole expected input).  finish() verifies that
-    // the bound was loose enough and reports MHX_E_CAPACITY otherwise.
-    uint64_t T = sk->hash_max;
-    if (sk->m > 1 && sk->expected_bytes > sk->nslots / 4) {
-        // at most 256*s admissions over the whole expected input: stays exact up to ~256x
-        // coverage (the s-th qualifying hash sits near s/D for D distinct solid k-mers, and the
-        // input holds about coverage*D windows), and duplicates keep the table far emptier
-        const long double frac = (long double)(256.0L * sk->s * sk->admit_scale) / (long double)sk->expected_bytes;
-        if (frac < 1.0L) T = (uint64_t)(frac * (long double)sk->hash_max);
-    }
-    sk->t_init = T;
-    sk->last_T = T;
-    // t_init lives in the sketcher and is only written here, so the copy may stay in flight
+    // Admission threshold: everything is admitted at first.  For m = 1 the first tighten pass already
+    // finds s entries; for m > 1 push_device keeps the table safe until s solid hashes exist.
+    sk->t_init = sk->hash_max;
+    sk->last_T = sk->hash_max;
+    sk->bounded = false;
+    sk->established = false;
+    sk->occupied = 0;
+    // t_init lives in the sketcher and is only written at creation, so the copy may stay in flight
     HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
     uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
     if (c0 < (256u << 10)) c0 = 256u << 10;
+    if (sk->m > 1 && c0 < (4u << 20)) c0 = 4u << 20; // the cap of push_device limits admissions there: start with a larger stage
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
     sk->next_chunk_bytes = c0;
     sk->settled = false;
@@ -298,10 +298,14 @@ extern "C" void mhx_sketcher_destroy(mhx_sketcher *sk)
 }
 
 static int read_threshold(mhx_sketcher *sk, uint64_t *T)
-{
+{ // after a tighten pass: the threshold and the table occupancy that pass measured
+    uint64_t occ = 0;
     HIPCHK(hipMemcpyAsync(T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(&occ, sk->d_stats + kStatOccupied, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    if (*T < sk->last_T && sk->m > 1) sk->established = true; // only the tighten pass lowers T between host writes
     sk->last_T = *T;
+    sk->occupied = occ;
     return MHX_OK;
 }
 
@@ -352,6 +356,25 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             const uint64_t chunk_tiles = (sk->next_chunk_bytes + kTileBytes - 1) / kTileBytes;
             if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
         }
+        if (sk->m > 1 && !sk->established) {
+            // Multiplicity filter: T cannot follow the data before s hashes with count >= m exist, and until
+            // then every admitted k-mer costs two atomics and may be a new table entry.  T is therefore capped
+            // at 48*s / (bytes seen after this launch), i.e. ~20*s admissions per x4 stage.  The cap stays above
+            // the final s-th solid hash for any genome size while the error-free k-mer coverage c so far is
+            // <= ~17x, and s solid hashes appear below it as soon as c / P[Poisson(c) >= m] <= 17 (c in
+            // 0.8 .. 16 for m = 3), a window no x4 stage can jump over.  Inputs with fewer than s solid k-mers in
+            // total, or m > ~8, end in finish()'s exactness check and the retry with a 16x budget.
+            const uint64_t after = sk->bytes_pushed + (uint64_t)take * kTileBytes;
+            const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
+            const long double cap_frac = (long double)(48.0L * sk->s * sk->admit_scale) / (long double)after;
+            if (cap_frac < t_frac) {
+                sk->t_write = (uint64_t)(cap_frac * (long double)sk->hash_max);
+                HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_write, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+                HIPCHK(hipStreamSynchronize(g.stream)); // t_write is reused by the next launch
+                sk->last_T = sk->t_write;
+                sk->bounded = true;
+            }
+        }
         a.tile0 = tile;
         a.ntiles = take;
         a.ticket = sk->d_tickets + launch;
@@ -378,8 +401,11 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             const uint64_t total = sk->expected_bytes > sk->bytes_pushed ? sk->expected_bytes : (uint64_t)ntiles * kTileBytes;
             const uint64_t remaining = total > sk->bytes_pushed ? total - sk->bytes_pushed : (uint64_t)(ntiles - tile) * kTileBytes;
             const long double admit = (long double)remaining * ((long double)T / (long double)sk->hash_max);
-            if (admit <= (long double)(sk->nslots / 8)) { sk->settled = true; sk->settled_total = total > sk->bytes_pushed ? total : sk->bytes_pushed; }
-            else sk->next_chunk_bytes *= kChunkGrowth;
+            // (with a multiplicity filter only once T comes from solid hashes: a host-imposed cap must keep
+            // following the input in x4 stages, or it would drop below the final s-th solid hash)
+            const bool may_settle = sk->m == 1 || sk->established;
+            if (may_settle && admit <= (long double)(sk->nslots / 8)) { sk->settled = true; sk->settled_total = total > sk->bytes_pushed ? total : sk->bytes_pushed; }
+            else sk->next_chunk_bytes *= (sk->m > 1 && !sk->established) ? 4 : kChunkGrowth; // x4 stages until solid hashes exist
         }
     }
     return MHX_OK;
@@ -597,7 +623,7 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
         cnts.push_back((uint32_t)maxkey);
     }
     // exactness: either nothing was ever rejected, or at least s qualifying hashes lie below T
-    if (keys.size() < sk->s && sk->t_init != sk->hash_max)
+    if (keys.size() < sk->s && sk->bounded)
         return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries); recreate the sketcher with a larger table",
                     keys.size(), sk->s);
     sort_pairs(keys, cnts);

@@ -476,3 +476,25 @@ def test_strand_decision_exact_path_on_device(k):
     sk.close()
     want, wcnt = mo.bruteforce_sketch(reads, k, 5000, 1)
     assert np.array_equal(got, want) and np.array_equal(cnt, wcnt)
+
+
+@pytest.mark.parametrize("coverage,s,m", [(300, 5000, 3), (40, 20000, 3), (2, 1000, 3), (150, 2000, 5)])
+def test_multiplicity_filter_is_exact_at_any_coverage(coverage, s, m):
+    """m > 1: before s solid hashes exist the admission threshold is capped from the bytes seen so far
+    (not from the expected total), so deep samples of small genomes stay exact without a retry; very
+    shallow ones (fewer than s solid k-mers) too."""
+    import torch
+
+    genome = synth.make_genome(200_000, seed=31)
+    n_reads = coverage * 200_000 // 150
+    fq = synth.make_fastq(genome, n_reads, 150, seed=32, device="cuda")
+    torch.cuda.synchronize()
+    sk = engine.Sketcher(21, s, m, expected_bytes=fq.numel())
+    sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)
+    got, cnt = sk.finish()
+    sk.close()
+    ref = mo.Sketcher(21, s, m)
+    ref.add_fastx(fq.cpu().numpy().tobytes())
+    want, want_cnt = ref.finish()
+    assert np.array_equal(got, want)
+    assert cnt.min() >= m if len(cnt) else True
