@@ -29,7 +29,7 @@ struct TableArgs {
     uint64_t nslots;
     uint64_t *thresh;
     uint32_t *hist;      // kHistBins counters, zero between rounds
-    uint64_t *acc;       // 2 accumulators of the tighten pass (occupied, solid), zero between rounds
+    uint64_t *acc;       // kAccReplicas x 8 words: accumulators of the tighten pass (occupied, solid), zero between rounds
     uint64_t *stats;
     uint32_t min_mult;
     uint32_t sketch_size;

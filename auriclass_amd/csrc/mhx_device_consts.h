@@ -43,5 +43,6 @@ enum Stat : int {
 constexpr int kStatReplicas = 64; // counters are replicated to spread atomic traffic
 
 constexpr int kHistBins = 2048;
+constexpr int kAccReplicas = 64; // tighten-pass accumulators (occupied, solid): one 64-byte line per replica
 
 } // namespace mhx

@@ -216,7 +216,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     HIPCHK(hipMemsetAsync(sk->d_keys, 0xFF, sk->nslots * sizeof(uint64_t), g.stream));
     HIPCHK(hipMemsetAsync(sk->d_cnts, 0, sk->nslots * sizeof(uint32_t), g.stream));
     HIPCHK(hipMemsetAsync(sk->d_hist, 0, kHistBins * sizeof(uint32_t), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_acc, 0, 2 * sizeof(uint64_t), g.stream));
+    HIPCHK(hipMemsetAsync(sk->d_acc, 0, kAccReplicas * 8 * sizeof(uint64_t), g.stream));
     HIPCHK(hipMemsetAsync(sk->d_stats, 0, kStatReplicas * kStatCount * sizeof(uint64_t), g.stream));
     // Admission threshold: everything is admitted at first.  For m = 1 the first tighten pass already
     // finds s entries; for m > 1 push_device keeps the table safe until s solid hashes exist.
@@ -270,7 +270,7 @@ static int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expect
     A((void **)&sk->d_cnts, sk->nslots * sizeof(uint32_t));
     A((void **)&sk->d_thresh, sizeof(uint64_t));
     A((void **)&sk->d_hist, kHistBins * sizeof(uint32_t));
-    A((void **)&sk->d_acc, 2 * sizeof(uint64_t));
+    A((void **)&sk->d_acc, kAccReplicas * 8 * sizeof(uint64_t));
     A((void **)&sk->d_stats, kStatReplicas * kStatCount * sizeof(uint64_t));
     A((void **)&sk->d_tickets, kMaxLaunchesPerPush * sizeof(uint32_t));
     A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));

@@ -310,8 +310,11 @@ __global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
     for (int i = threadIdx.x; i < kHistBins; i += blockDim.x)
         if (h[i]) atomicAdd(&a.hist[i], h[i]);
     if (threadIdx.x == 0) {
-        if (occ_s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.acc[0]), (unsigned long long)occ_s);
-        if (solid_s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.acc[1]), (unsigned long long)solid_s);
+        // 64 replicas, 64 bytes apart: a thousand workgroups adding to ONE word serialise at ~10-20 ns each,
+        // which was most of this kernel's 33 us
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.acc) + (blockIdx.x % kAccReplicas) * 8;
+        if (occ_s) atomicAdd(&acc[0], (unsigned long long)occ_s);
+        if (solid_s) atomicAdd(&acc[1], (unsigned long long)solid_s);
     }
 }
 
@@ -342,10 +345,15 @@ __global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
     a.hist[2 * t + 1] = 0;
     __syncthreads();
     if (t == 0) { // publish this pass's totals (replica 0), clear the accumulators
-        a.stats[kStatOccupied] = a.acc[0] * (a.sample > 1 ? a.sample : 1);
-        a.stats[kStatSolid] = a.acc[1] * (a.sample > 1 ? a.sample : 1);
-        a.acc[0] = 0;
-        a.acc[1] = 0;
+        uint64_t occ = 0, solid = 0;
+        for (int r = 0; r < kAccReplicas; ++r) {
+            occ += a.acc[r * 8];
+            solid += a.acc[r * 8 + 1];
+            a.acc[r * 8] = 0;
+            a.acc[r * 8 + 1] = 0;
+        }
+        a.stats[kStatOccupied] = occ * (a.sample > 1 ? a.sample : 1);
+        a.stats[kStatSolid] = solid * (a.sample > 1 ? a.sample : 1);
     }
     if (t == 0 && cut != 0xFFFFFFFFu) {
         const uint64_t T = *a.thresh;
