@@ -924,8 +924,8 @@ class ChunkQueue {
 struct FileIngestState {
     std::string error;
     uint64_t lines = 0, bytes = 0;
-    uint64_t counted = 0; // records whose sequence line holds >= k bases (mash's `count`)
     bool not_fastq4 = false;
+    bool own_inflate_failed = false; // the engine's own DEFLATE decoder refused the stream
 };
 
 static bool is_gzip_file(const char *path)
@@ -958,10 +958,10 @@ static bool read_whole_file(const char *path, std::vector<uint8_t> &out, size_t 
 // Producer of one input file: inflates it (own DEFLATE decoder on the whole compressed file in memory;
 // MHX_ZLIB_INFLATE=1 selects zlib's gzread instead; an uncompressed file is simply read) and cuts the
 // stream into record-aligned chunks.
-void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *st)
+void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, FileIngestState *st)
 {
     const bool gz = is_gzip_file(path);
-    const bool own = gz && !getenv("MHX_ZLIB_INFLATE");
+    const bool own = gz && !force_zlib && !getenv("MHX_ZLIB_INFLATE");
     gzFile g = nullptr;
     FILE *plain = nullptr;
     std::vector<uint8_t> zbytes;
@@ -1004,7 +1004,13 @@ void inflate_fastq(const char *path, int file, ChunkQueue *q, FileIngestState *s
                 got = (long)fread(d + n, 1, kIngestChunk - n, plain);
                 if (got == 0 && ferror(plain)) got = -1;
             }
-            if (got < 0) { st->error = std::string("ERROR: reading ") + path + " failed"; close_all(); q->producer_done(); return; }
+            if (got < 0) {
+                st->error = std::string("ERROR: reading ") + path + " failed";
+                st->own_inflate_failed = own; // the caller repeats the run with zlib before giving up
+                close_all();
+                q->producer_done();
+                return;
+            }
             if (got == 0) { eof = true; break; }
             n += (size_t)got;
         }
@@ -1172,7 +1178,7 @@ static void first_counted_header(const uint8_t *buf, size_t n, int k, std::strin
 // *handled = false means "not strict FASTQ / could not size": use the whole-file path.
 static int stream_fastq_reference(const char *const *paths, int n_paths, int k, uint32_t s, uint32_t m, std::vector<uint64_t> &hashes,
                                   std::vector<uint32_t> &counts, uint64_t *kmers, uint64_t *records, std::string *fname,
-                                  std::string *fcomment, bool *handled)
+                                  std::string *fcomment, bool *handled, bool force_zlib = false)
 {
     *handled = false;
     uint64_t expected = 0;
@@ -1207,7 +1213,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         ChunkQueue q;
         std::vector<std::thread> threads;
         for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
-        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, &q, &st[i]);
+        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, &q, &st[i]);
         IngestChunk c;
         while (q.get(c)) {
             if (rc) continue; // drain
@@ -1221,6 +1227,14 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
             if (rc) q.abort();
         }
         for (auto &t : threads) t.join();
+    }
+    bool own_failed = false;
+    for (auto &f : st) own_failed = own_failed || f.own_inflate_failed;
+    if (own_failed && !force_zlib) { // the engine's own decoder refused a stream: let zlib have the last word
+        hipFree(d_slot);
+        mhx_sketcher_destroy(sk);
+        clear_error();
+        return stream_fastq_reference(paths, n_paths, k, s, m, hashes, counts, kmers, records, fname, fcomment, handled, true);
     }
     for (auto &f : st) {
         if (!f.error.empty() && !rc) rc = fail(MHX_E_IO, "%s", f.error.c_str());

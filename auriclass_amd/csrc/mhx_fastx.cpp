@@ -63,7 +63,7 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     size_t n = 0;
     for (;;) {
         const size_t r = inf.inflate(out.data() + n, out.size() - slack - n, out.data());
-        if (r == (size_t)-1) return fail(MHX_E_IO, "ERROR: reading %s failed (%s)", path, inf.error().c_str());
+        if (r == (size_t)-1) return read_all_zlib(path, out); // zlib has the last word on a stream this decoder refuses
         n += r;
         if (inf.done()) break;
         if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2); // more members than the hint covered

@@ -164,7 +164,11 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
 
     // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
     uint32_t tile;
+#ifdef MHX_NO_TICKET
+    if (false) {
+#else
     if (FASTQ) {
+#endif
         if (tid == 0) sm.misc[2] = a.tile0 + atomicAdd(a.ticket, 1u);
         __syncthreads();
         tile = sm.misc[2];

@@ -498,3 +498,18 @@ def test_multiplicity_filter_is_exact_at_any_coverage(coverage, s, m):
     want, want_cnt = ref.finish()
     assert np.array_equal(got, want)
     assert cnt.min() >= m if len(cnt) else True
+
+
+def test_corrupt_gz_is_reported_after_zlib_had_the_last_word(tmp_path):
+    """A .fq.gz the engine's own DEFLATE decoder refuses is run again through zlib; a stream that is
+    really broken then fails with mash's wording instead of producing a sketch."""
+    import gzip
+
+    genome = synth.make_genome(50_000, seed=41)
+    a = synth.make_fastq(genome, 20_000, 150, seed=42, device="cpu").numpy().tobytes()
+    p = tmp_path / "broken.fq.gz"
+    z = bytearray(gzip.compress(a, compresslevel=6))
+    z[len(z) // 2] ^= 0x55
+    p.write_bytes(bytes(z))
+    with pytest.raises(engine.EngineError):
+        engine.sketch_files([p], 21, 1000, tmp_path / "x.msh", reads=True, min_mult=1)
