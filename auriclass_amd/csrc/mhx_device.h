@@ -58,7 +58,10 @@ hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st);
 // all-vs-refs fast path (nr <= 32): value-range partition + LDS hash probe
 constexpr int kDistRanges = 1024;     // value ranges the hash space is cut into
 constexpr int kDistTableSlots = 2048; // LDS table of one range (refs' hashes of that range)
-constexpr int kDistQueryChunks = 4;   // query chunks per range (grid.y of the range kernel)
+#ifndef MHX_DIST_QCHUNKS
+#define MHX_DIST_QCHUNKS 4
+#endif
+constexpr int kDistQueryChunks = MHX_DIST_QCHUNKS;   // query chunks per range (grid.y of the range kernel)
 constexpr int kDistSegs = 16;         // finish kernel: ranges are summed in 16 segments first
 struct DistWork {
     uint32_t *offs_q;   // [nq][kDistRanges + 1] first index of every range in each query list

@@ -547,7 +547,6 @@ extern "C" int mhx_gunzip_buffer(const void *gz, size_t n, void *out, size_t cap
     memcpy(in.data(), gz, n);
     GzInflater inf;
     inf.set_input(in.data(), n);
-    if (getenv("MHX_GUNZIP_NOCRC")) inf.set_verify_crc(false);
     // decode in pieces into a scratch buffer with the 32 KiB history in front, counting first
     constexpr size_t kPiece = 1u << 20;
     std::vector<uint8_t> buf(GzInflater::kWindow + kPiece + GzInflater::kOvershoot + 16);

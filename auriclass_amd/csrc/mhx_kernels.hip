@@ -158,17 +158,10 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     __shared__ TileSmem sm;
     constexpr bool FASTQ = (FMT == 1);
     const int tid = threadIdx.x;
-#ifdef MHX_PRIO_PRE
-    __builtin_amdgcn_s_setprio(MHX_PRIO_PRE);
-#endif
 
     // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
     uint32_t tile;
-#ifdef MHX_NO_TICKET
-    if (false) {
-#else
     if (FASTQ) {
-#endif
         if (tid == 0) sm.misc[2] = a.tile0 + atomicAdd(a.ticket, 1u);
         __syncthreads();
         tile = sm.misc[2];

@@ -435,10 +435,7 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
     constexpr int OF = J;               // forward window starts at U byte OF
     constexpr int OR = ND * 4 - K - J;  // its reverse complement starts at R byte OR
     uint32_t w[8];
-#ifndef MHX_STRAND_FAST
-#define MHX_STRAND_FAST 1
-#endif
-    if constexpr (MHX_STRAND_FAST && K >= 8) {
+    if constexpr (K >= 8) {
         // memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most
         // significant first, are 8 little-endian bytes of Wr resp. Cc.  Equal first 8 bases
         // (4^-8 of the windows) fall back to the full comparison.
@@ -501,35 +498,6 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
     }
     U[ND] = R[ND] = Wr[ND] = Cc[ND] = 0;
     constexpr bool kHash32 = K <= 16; // mash keeps 32 bits when 4^k <= 2^32
-#ifndef MHX_BATCH_ADMIT
-#define MHX_BATCH_ADMIT 0
-#endif
-#if MHX_BATCH_ADMIT
-    // all eight hashes first (one straight-line block the scheduler can interleave), then ONE
-    // admission test: windows below the threshold are ~1e-4 of all, so the insert path is cold
-    uint64_t h[kGroup];
-    h[0] = window_hash<K, 0, ND>(U, R, Wr, Cc);
-    h[1] = window_hash<K, 1, ND>(U, R, Wr, Cc);
-    h[2] = window_hash<K, 2, ND>(U, R, Wr, Cc);
-    h[3] = window_hash<K, 3, ND>(U, R, Wr, Cc);
-    h[4] = window_hash<K, 4, ND>(U, R, Wr, Cc);
-    h[5] = window_hash<K, 5, ND>(U, R, Wr, Cc);
-    h[6] = window_hash<K, 6, ND>(U, R, Wr, Cc);
-    h[7] = window_hash<K, 7, ND>(U, R, Wr, Cc);
-    uint64_t lowest = ~0ull;
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-        if (kHash32) h[j] &= 0xFFFFFFFFull;
-        const uint64_t c = ((vm >> j) & 1u) ? h[j] : ~0ull;
-        lowest = c < lowest ? c : lowest;
-    }
-    uint32_t ninserted = 0;
-    if (lowest <= T && vm) {
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j)
-            if (((vm >> j) & 1u) && h[j] <= T) { ins(h[j]); ++ninserted; }
-    }
-#else
     uint32_t ninserted = 0;
 #define MHX_WINDOW(J)                                                    \
     {                                                                    \
@@ -539,7 +507,6 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
     }
     MHX_WINDOW(0) MHX_WINDOW(1) MHX_WINDOW(2) MHX_WINDOW(3) MHX_WINDOW(4) MHX_WINDOW(5) MHX_WINDOW(6) MHX_WINDOW(7)
 #undef MHX_WINDOW
-#endif
     static_assert(kGroup == 8, "process_group unrolls 8 windows");
     return ninserted;
 }
