@@ -181,6 +181,7 @@ static constexpr int kMaxLaunchesPerPush = 64;
 #define MHX_CHUNK_GROWTH 16
 #endif
 static constexpr uint64_t kChunkGrowth = MHX_CHUNK_GROWTH; // chunk size ratio between tighten rounds
+static constexpr uint64_t kUncappedBytes = 1u << 20;       // m > 1: prefix of the input that is admitted whole
 
 static TableArgs table_args(mhx_sketcher *sk)
 {
@@ -229,7 +230,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
     uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
     if (c0 < (256u << 10)) c0 = 256u << 10;
-    if (sk->m > 1 && c0 < (4u << 20)) c0 = 4u << 20; // the cap of push_device limits admissions there: start with a larger stage
+    if (sk->m > 1) c0 = kUncappedBytes; // multiplicity filter: the first stage is admitted whole (see push_device)
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
     sk->next_chunk_bytes = c0;
     sk->settled = false;
@@ -358,21 +359,26 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         }
         if (sk->m > 1 && !sk->established) {
             // Multiplicity filter: T cannot follow the data before s hashes with count >= m exist, and until
-            // then every admitted k-mer costs two atomics and may be a new table entry.  T is therefore capped
-            // at 48*s / (bytes seen after this launch), i.e. ~20*s admissions per x4 stage.  The cap stays above
-            // the final s-th solid hash for any genome size while the error-free k-mer coverage c so far is
-            // <= ~17x, and s solid hashes appear below it as soon as c / P[Poisson(c) >= m] <= 17 (c in
-            // 0.8 .. 16 for m = 3), a window no x4 stage can jump over.  Inputs with fewer than s solid k-mers in
-            // total, or m > ~8, end in finish()'s exactness check and the retry with a 16x budget.
+            // then every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is
+            // admitted whole (small genomes and saturated k-mer spaces show their solid hashes there); after
+            // that T is capped at 48*s' / (bytes seen after this launch), s' = s + 8*sqrt(s) + 16, i.e. ~20*s
+            // admissions per x4 stage.  The cap stays above the final s-th solid hash for any genome size while
+            // the error-free k-mer coverage c so far is <= ~17x, and s solid hashes appear below it as soon as
+            // c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window no x4 stage can jump over.
+            // Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s exactness check and
+            // the retry with a 16x budget.
             const uint64_t after = sk->bytes_pushed + (uint64_t)take * kTileBytes;
-            const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
-            const long double cap_frac = (long double)(48.0L * sk->s * sk->admit_scale) / (long double)after;
-            if (cap_frac < t_frac) {
-                sk->t_write = (uint64_t)(cap_frac * (long double)sk->hash_max);
-                HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_write, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-                HIPCHK(hipStreamSynchronize(g.stream)); // t_write is reused by the next launch
-                sk->last_T = sk->t_write;
-                sk->bounded = true;
+            if (after > kUncappedBytes) {
+                const long double s_eff = (long double)sk->s + 8.0L * sqrtl((long double)sk->s) + 16.0L;
+                const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
+                const long double cap_frac = 48.0L * s_eff * (long double)sk->admit_scale / (long double)after;
+                if (cap_frac < t_frac) {
+                    sk->t_write = (uint64_t)(cap_frac * (long double)sk->hash_max);
+                    HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_write, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+                    HIPCHK(hipStreamSynchronize(g.stream)); // t_write is reused by the next launch
+                    sk->last_T = sk->t_write;
+                    sk->bounded = true;
+                }
             }
         }
         a.tile0 = tile;

@@ -513,3 +513,58 @@ def test_corrupt_gz_is_reported_after_zlib_had_the_last_word(tmp_path):
     p.write_bytes(bytes(z))
     with pytest.raises(engine.EngineError):
         engine.sketch_files([p], 21, 1000, tmp_path / "x.msh", reads=True, min_mult=1)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
+    """Random k (1..32), sketch size, multiplicity, read-length distribution, N / lower-case content,
+    CRLF or LF, number of pushes and device-pointer alignment; every case against the oracle, counts
+    and record count included."""
+    import torch
+
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(1, 33))
+    m = int(rng.choice([1, 1, 2, 3, 4]))
+    s = int(rng.choice([1, 50, 1000, 20000]))
+    genome = synth.make_genome(int(rng.integers(2_000, 60_000)), seed=seed)
+    n_reads = int(rng.integers(200, 6000))
+    lo, hi = sorted(int(x) for x in rng.integers(1, 300, 2))
+    reads = []
+    for _ in range(n_reads):
+        L = int(rng.integers(lo, hi + 1))
+        p0 = int(rng.integers(0, len(genome) - L))
+        r = bytearray(genome[p0:p0 + L].tobytes())
+        if rng.random() < 0.2 and L:
+            r[int(rng.integers(0, L))] = ord(rng.choice(list("NRYKMSW")))
+        r = bytes(r)
+        reads.append(r.lower() if rng.random() < 0.15 else r)
+    nl = b"\r\n" if rng.random() < 0.25 else b"\n"
+    quals = np.frombuffer(b"!#+@ACGTIJ5<?acgt", np.uint8)
+    recs = [b"@r%d d" % i + nl + r + nl + b"+" + nl + bytes(rng.choice(quals, size=len(r))) + nl for i, r in enumerate(reads)]
+    n_push = int(rng.integers(1, 5))
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(recs) + 1, n_push - 1))) if n_push > 1 else []
+    bounds = [0] + cuts + [len(recs)]
+    total = sum(len(r) for r in recs)
+    sk = engine.Sketcher(k, s, m, expected_bytes=total if rng.random() < 0.7 else 0)
+    keep = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        blob = b"".join(recs[a:b])
+        if not blob:
+            continue
+        lead = int(rng.integers(0, 40))
+        dev = torch.zeros(len(blob) + lead + 64, dtype=torch.uint8, device="cuda")
+        dev[lead:lead + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        keep.append(dev)
+        sk.push_device(dev.data_ptr() + lead, len(blob), engine.FMT_FASTQ4)
+    got, got_c = sk.finish()
+    n_long = sk.record_count()
+    sk.close()
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(b"".join(recs))
+    want, want_c = ref.finish()
+    assert np.array_equal(got, want), (k, s, m)
+    assert n_long == ref.records == sum(1 for r in reads if len(r) >= k)
+    if m == 1:     # with m > 1 mash's own counts depend on the insertion order (DESIGN.md §6); exact here
+        brute_h, brute_c = mo.bruteforce_sketch([r for r in reads], k, s, m)
+        assert np.array_equal(got_c, brute_c)
