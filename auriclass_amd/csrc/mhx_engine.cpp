@@ -174,6 +174,7 @@ struct mhx_sketcher {
     bool bounded = false;      // a host-imposed bound has limited T at least once
     bool established = false;  // the tighten pass has lowered T from solid (count >= m) entries
     uint64_t occupied = 0;     // table occupancy reported by the last tighten pass
+    uint64_t solid = 0;        // entries <= T with count >= m reported by the last tighten pass
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
@@ -226,6 +227,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     sk->bounded = false;
     sk->established = false;
     sk->occupied = 0;
+    sk->solid = 0;
     // t_init lives in the sketcher and is only written at creation, so the copy may stay in flight
     HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
     uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
@@ -300,13 +302,15 @@ extern "C" void mhx_sketcher_destroy(mhx_sketcher *sk)
 
 static int read_threshold(mhx_sketcher *sk, uint64_t *T)
 { // after a tighten pass: the threshold and the table occupancy that pass measured
-    uint64_t occ = 0;
+    static_assert(kStatSolid == kStatOccupied + 1, "occupied and solid are read with one copy");
+    uint64_t occ_solid[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(&occ, sk->d_stats + kStatOccupied, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(occ_solid, sk->d_stats + kStatOccupied, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     if (*T < sk->last_T && sk->m > 1) sk->established = true; // only the tighten pass lowers T between host writes
     sk->last_T = *T;
-    sk->occupied = occ;
+    sk->occupied = occ_solid[0];
+    sk->solid = occ_solid[1];
     return MHX_OK;
 }
 
@@ -354,7 +358,14 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         uint32_t take = ntiles - tile;
         const bool last_slot = launch == kMaxLaunchesPerPush - 1;
         if (!sk->settled && !last_slot) {
-            const uint64_t chunk_tiles = (sk->next_chunk_bytes + kTileBytes - 1) / kTileBytes;
+            uint64_t chunk_bytes = sk->next_chunk_bytes;
+            if (sk->m > 1 && !sk->established) {
+                // stages of the capped phase are defined on the bytes actually seen (pushes may be of any size):
+                // the uncapped first MiB, then never more than x4 cumulative growth per launch
+                const uint64_t rest_of_prefix = sk->bytes_pushed < kUncappedBytes ? kUncappedBytes - sk->bytes_pushed : 0;
+                chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * sk->bytes_pushed);
+            }
+            const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
             if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
         }
         if (sk->m > 1 && !sk->established) {
@@ -367,8 +378,11 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             // c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window no x4 stage can jump over.
             // Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s exactness check and
             // the retry with a 16x budget.
+            // No cap while the input looks like a small genome sequenced deeply (a fifth of the table entries
+            // are solid already, yet fewer than s of them): its sketch may need every solid hash there is.
             const uint64_t after = sk->bytes_pushed + (uint64_t)take * kTileBytes;
-            if (after > kUncappedBytes) {
+            const bool saturating = sk->occupied > 0 && sk->solid * 5 >= sk->occupied;
+            if (after > kUncappedBytes && !saturating) {
                 const long double s_eff = (long double)sk->s + 8.0L * sqrtl((long double)sk->s) + 16.0L;
                 const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
                 const long double cap_frac = 48.0L * s_eff * (long double)sk->admit_scale / (long double)after;

@@ -9,6 +9,10 @@ from tests.conftest import GOLDEN, REFDATA
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+FUZZ = int(os.environ.get("MHX_FUZZ_SCALE", "1"))   # MHX_FUZZ_SCALE=10: ten times the randomised cases
+
 
 @pytest.fixture(scope="module", autouse=True)
 def _engine():
@@ -515,7 +519,7 @@ def test_corrupt_gz_is_reported_after_zlib_had_the_last_word(tmp_path):
         engine.sketch_files([p], 21, 1000, tmp_path / "x.msh", reads=True, min_mult=1)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * FUZZ))
 def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
     """Random k (1..32), sketch size, multiplicity, read-length distribution, N / lower-case content,
     CRLF or LF, number of pushes and device-pointer alignment; every case against the oracle, counts
@@ -568,3 +572,70 @@ def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
     if m == 1:     # with m > 1 mash's own counts depend on the insertion order; exact here
         brute_h, brute_c = mo.bruteforce_sketch([r for r in reads], k, s, m)
         assert np.array_equal(got_c, brute_c)
+
+
+@pytest.mark.parametrize("seed", range(8 * FUZZ))
+def test_randomised_file_level_reads_mode(tmp_path, seed):
+    """Random mixes of plain and gzipped FASTQ files (1..3 files, some empty of long reads, some with
+    CRLF, some without a final newline) through mhx_sketch_files in reads mode: .msh bytes and the
+    stderr text against the oracle."""
+    import gzip
+
+    rng = np.random.default_rng(8100 + seed)
+    k = int(rng.choice([11, 16, 21, 27, 32]))
+    s = int(rng.choice([200, 1000, 50000]))
+    m = int(rng.choice([1, 2, 3]))
+    genome = synth.make_genome(int(rng.integers(5_000, 80_000)), seed=100 + seed)
+    paths, blobs = [], []
+    for fi in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(300, 4000))
+        L = int(rng.integers(30, 260))
+        data = synth.make_fastq(genome, n, L, seed=int(rng.integers(1, 10_000)), device="cpu", first_index=fi * 10_000).numpy().tobytes()
+        if rng.random() < 0.3:
+            data = b"@s1\nAC\n+\nII\n" + data                      # a record mash skips (shorter than k)
+        if rng.random() < 0.3:
+            data = data.replace(b"\n", b"\r\n")
+        if rng.random() < 0.3:
+            data = data[:-1] if not data.endswith(b"\r\n") else data[:-2]
+        p = tmp_path / ("f%d.fq" % fi)
+        if rng.random() < 0.5:
+            p = tmp_path / ("f%d.fq.gz" % fi)
+            with gzip.open(p, "wb", compresslevel=int(rng.integers(1, 10))) as fh:
+                fh.write(data)
+        else:
+            p.write_bytes(data)
+        paths.append(p)
+        blobs.append(data)
+    stderr, est = engine.sketch_files(paths, k, s, tmp_path / "o.msh", reads=True, min_mult=m)
+    ref = mo.Sketcher(k, s, m)
+    for b in blobs:
+        ref.add_fastx(b)
+    want, _ = ref.finish()
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert np.array_equal(got.hashes, want), (k, s, m)
+    assert got.comment == ref.comment()
+    assert got.length == int(ref.set_size)
+    assert "Estimated genome size: %g\n" % ref.set_size in stderr
+
+
+@pytest.mark.parametrize("seed", range(6 * FUZZ))
+def test_randomised_dist_batches(seed):
+    """Random batch shapes for mash's compareSketches on the device: 1..40 references (both sides of the
+    32-reference fast path), ragged list lengths, shared fractions from 0 to 1, tiny and full sketches."""
+    rng = np.random.default_rng(8200 + seed)
+    s = int(rng.choice([64, 1000, 5000]))
+    k = int(rng.choice([16, 21, 27]))
+    hi = 2 ** 32 if k <= 16 else 2 ** 64
+    nr = int(rng.integers(1, 41))
+    nq = int(rng.integers(1, 90))
+    base = _sketch_like(rng, 3 * s, hi)
+    refs = [np.sort(rng.choice(base, size=int(rng.integers(1, s + 1)), replace=False)) for _ in range(nr)]
+    qrys = []
+    for _ in range(nq):
+        src = refs[int(rng.integers(0, nr))]
+        f = rng.random()
+        keep = src[rng.random(len(src)) >= f]
+        fresh = _sketch_like(rng, int(rng.integers(0, s // 2 + 1)), hi)
+        q = np.unique(np.concatenate([keep, fresh]))[: s]
+        qrys.append(q)
+    _check_all_pairs(qrys, refs, k, s)
