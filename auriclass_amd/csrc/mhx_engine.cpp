@@ -294,6 +294,11 @@ extern "C" int mhx_sketcher_create(int k, uint32_t s, uint32_t min_mult, uint64_
     return create_sketcher(k, s, min_mult, expected_bytes, 1, out);
 }
 
+extern "C" int mhx_sketcher_create_scaled(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint32_t budget_scale, mhx_sketcher **out)
+{
+    return create_sketcher(k, s, min_mult, expected_bytes, budget_scale ? budget_scale : 1, out);
+}
+
 extern "C" void mhx_sketcher_destroy(mhx_sketcher *sk)
 {
     if (g.ready) hipStreamSynchronize(g.stream);
@@ -1207,8 +1212,12 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     int rc = mhx_sketcher_create(k, s, m, expected, &sk);
     if (rc) return rc;
     bool fallback = false, have_header = false;
-    // 1. uncompressed files: whole file -> one device buffer -> one push (see bulk_load_plain)
+    // 1. uncompressed files: whole file -> one device buffer -> one push (see bulk_load_plain).  The buffers
+    // stay on the device until the sketch is final, so that a too-small admission budget can be repaired by
+    // pushing them again into a larger sketcher instead of reading the files a second time.
     std::vector<int> queued; // files that go through an inflate thread instead
+    std::vector<BulkFile> resident;
+    auto free_resident = [&]() { for (auto &b : resident) hipFree(b.d_buf); resident.clear(); };
     for (int i = 0; i < n_paths && !rc && !fallback; ++i) {
         if (is_gzip_file(paths[i]) || getenv("MHX_NO_BULK")) { queued.push_back(i); continue; }
         BulkFile bf;
@@ -1222,7 +1231,8 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         }
         if (!fallback) rc = mhx_sketcher_push_device(sk, bf.d_buf, bf.size, MHX_FMT_FASTQ4);
         if (hipStreamSynchronize(g.stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "stream sync failed");
-        hipFree(bf.d_buf);
+        bf.head.clear();
+        resident.push_back(std::move(bf));
     }
     // 2. compressed files: one inflate thread per file, 32 MiB record-aligned chunks
     uint8_t *d_slot = nullptr;
@@ -1252,6 +1262,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     for (auto &f : st) own_failed = own_failed || f.own_inflate_failed;
     if (own_failed && !force_zlib) { // the engine's own decoder refused a stream: let zlib have the last word
         hipFree(d_slot);
+        free_resident();
         mhx_sketcher_destroy(sk);
         clear_error();
         return stream_fastq_reference(paths, n_paths, k, s, m, hashes, counts, kmers, records, fname, fcomment, handled, true);
@@ -1265,6 +1276,18 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         hashes.resize(s);
         counts.resize(s);
         rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
+        // admission budget too small (few solid k-mers: the sketch needs hashes the cap rejected): when every
+        // input is still resident on the device, push it again into a sketcher with 16x, 256x ... the budget
+        uint32_t scale = 1;
+        while (rc == MHX_E_CAPACITY && queued.empty() && !resident.empty() && scale < (1u << 20)) {
+            scale *= 16;
+            clear_error();
+            mhx_sketcher_destroy(sk);
+            sk = nullptr;
+            rc = create_sketcher(k, s, m, expected, scale, &sk);
+            for (size_t i = 0; i < resident.size() && !rc; ++i) rc = mhx_sketcher_push_device(sk, resident[i].d_buf, resident[i].size, MHX_FMT_FASTQ4);
+            if (!rc) rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
+        }
         if (rc == MHX_E_FORMAT || rc == MHX_E_CAPACITY) { fallback = true; rc = MHX_OK; clear_error(); }
     }
     if (!rc && !fallback) {
@@ -1277,7 +1300,8 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         *handled = !rc;
     }
     hipFree(d_slot);
-    mhx_sketcher_destroy(sk);
+    free_resident();
+    if (sk) mhx_sketcher_destroy(sk);
     return rc;
 }
 

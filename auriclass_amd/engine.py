@@ -85,6 +85,7 @@ def load() -> ctypes.CDLL:
     L.mhx_sniff_fastq.argtypes = [c.c_char_p]
     L.mhx_sniff_fasta.argtypes = [c.c_char_p]
     L.mhx_sketcher_create.argtypes = [c.c_int, c.c_uint32, c.c_uint32, c.c_uint64, c.POINTER(c.c_void_p)]
+    L.mhx_sketcher_create_scaled.argtypes = [c.c_int, c.c_uint32, c.c_uint32, c.c_uint64, c.c_uint32, c.POINTER(c.c_void_p)]
     L.mhx_sketcher_destroy.argtypes = [c.c_void_p]
     L.mhx_sketcher_destroy.restype = None
     L.mhx_sketcher_reset.argtypes = [c.c_void_p]
@@ -223,11 +224,11 @@ def msh_write(path, k: int, s: int, names: Sequence[str], comments: Sequence[str
 class Sketcher:
     """Device sketch accumulator (one reference)."""
 
-    def __init__(self, k: int, s: int, min_mult: int = 1, expected_bytes: int = 0):
+    def __init__(self, k: int, s: int, min_mult: int = 1, expected_bytes: int = 0, budget_scale: int = 1):
         init()
         self.k, self.s, self.m = k, s, max(1, min_mult)
         h = ctypes.c_void_p()
-        _check(load().mhx_sketcher_create(k, s, self.m, expected_bytes, ctypes.byref(h)))
+        _check(load().mhx_sketcher_create_scaled(k, s, self.m, expected_bytes, budget_scale, ctypes.byref(h)))
         self._h = h
 
     def close(self) -> None:

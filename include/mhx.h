@@ -83,6 +83,11 @@ typedef struct mhx_sketcher mhx_sketcher;
 /* expected_bytes: upper bound of the bytes that will be pushed (sizes the device
  * candidate table and the initial admission threshold); 0 = unknown/small. */
 int mhx_sketcher_create(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, mhx_sketcher **out);
+/* Same with budget_scale times the candidate table and admission budget: what a caller asks for after
+ * finish() has reported MHX_E_CAPACITY (inputs whose solid k-mers are fewer than s when min_mult > 1;
+ * the file-level call retries with 16, 256, ... by itself). */
+int mhx_sketcher_create_scaled(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint32_t budget_scale,
+                               mhx_sketcher **out);
 void mhx_sketcher_destroy(mhx_sketcher *sk);
 int mhx_sketcher_reset(mhx_sketcher *sk);
 

@@ -639,3 +639,73 @@ def test_randomised_dist_batches(seed):
         q = np.unique(np.concatenate([keep, fresh]))[: s]
         qrys.append(q)
     _check_all_pairs(qrys, refs, k, s)
+
+
+@pytest.mark.parametrize("seed", range(5 * FUZZ))
+def test_randomised_medium_inputs_with_multiplicity_filter(seed):
+    """3-60 MB inputs (hundreds to thousands of tiles, several tighten stages) over random genome sizes
+    and coverages from well below 1x to a few hundred x, m in 1..5, s from 100 to 50000, one to three
+    pushes: the capped-admission phase and the look-back at scale."""
+    rng = np.random.default_rng(8300 + seed)
+    k = int(rng.choice([15, 21, 27, 31]))
+    m = int(rng.choice([1, 2, 3, 3, 5]))
+    s = int(rng.choice([100, 1000, 5000, 50000]))
+    genome = synth.make_genome(int(10 ** rng.uniform(4.0, 6.5)), seed=200 + seed)
+    L = int(rng.choice([75, 100, 150, 250]))
+    n_reads = int(10 ** rng.uniform(4.0, 5.3))
+    fq = synth.make_fastq(genome, n_reads, L, seed=300 + seed, device="cuda", sub_rate=float(rng.choice([0.0, 0.005, 0.02])))
+    import torch
+
+    torch.cuda.synchronize()
+    rb = synth.record_bytes(L)
+    n_push = int(rng.integers(1, 4))
+    cuts = sorted(set(int(x) for x in rng.integers(1, n_reads, n_push - 1))) if n_push > 1 else []
+    bounds = [0] + cuts + [n_reads]
+    expected = fq.numel() if rng.random() < 0.7 else 0
+    for scale in (1, 16, 256, 4096):
+        # inputs with fewer than s solid k-mers need every one of them: the engine says so (MHX_E_CAPACITY) and the
+        # caller repeats with a larger admission budget, as mhx_sketch_files does by itself
+        sk = engine.Sketcher(k, s, m, expected_bytes=expected, budget_scale=scale)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            sk.push_device(fq.data_ptr() + a * rb, (b - a) * rb, engine.FMT_FASTQ4)
+        try:
+            got, _ = sk.finish()
+        except engine.EngineError as e:
+            sk.close()
+            if e.code != engine.MHX_E_CAPACITY:
+                raise
+            continue
+        assert sk.record_count() == (n_reads if L >= k else 0)
+        sk.close()
+        break
+    else:
+        raise AssertionError("no admission budget was large enough")
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(fq.cpu().numpy().tobytes())
+    want, _ = ref.finish()
+    assert np.array_equal(got, want), (k, s, m, len(genome), n_reads, L)
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_shallow_sample_with_multiplicity_filter_needs_every_solid_kmer(tmp_path, gz):
+    """0.06x coverage with m = 3: only a few hundred k-mers are solid, fewer than s, so the sketch is ALL of
+    them and the capped admission must be repeated with a larger budget: in place from the device-resident
+    buffers for a plain file, through the whole-file path for a .gz."""
+    import gzip
+
+    genome = synth.make_genome(40_000_000, seed=51)
+    data = synth.make_fastq(genome, 16_000, 150, seed=52, device="cpu").numpy().tobytes()      # 5 MB, 0.06x
+    p = tmp_path / ("shallow.fq.gz" if gz else "shallow.fq")
+    if gz:
+        with gzip.open(p, "wb", compresslevel=4) as fh:
+            fh.write(data)
+    else:
+        p.write_bytes(data)
+    engine.sketch_files([p], 21, 1000, tmp_path / "o.msh", reads=True, min_mult=3)
+    ref = mo.Sketcher(21, 1000, 3)
+    ref.add_fastx(data)
+    want, _ = ref.finish()
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert 0 < len(want) < 1000
+    assert np.array_equal(got.hashes, want)
+    assert got.comment == ref.comment()
