@@ -709,3 +709,103 @@ def test_shallow_sample_with_multiplicity_filter_needs_every_solid_kmer(tmp_path
     assert 0 < len(want) < 1000
     assert np.array_equal(got.hashes, want)
     assert got.comment == ref.comment()
+
+
+@pytest.mark.parametrize("seed", range(6 * FUZZ))
+def test_randomised_sequence_streams_with_arbitrary_bytes(seed):
+    """MHX_FMT_SEQ: any byte that is not A/C/G/T (either case) ends a k-mer run -- newlines, NUL, 0xFF,
+    '>', '@', CR, digits.  Random streams with such bytes sprinkled in, random k / s / m, random split into
+    pushes at record separators; against the brute-force definition."""
+    import re
+
+    rng = np.random.default_rng(8400 + seed)
+    k = int(rng.integers(1, 33))
+    s = int(rng.choice([1, 100, 2000]))
+    m = int(rng.choice([1, 1, 2, 3]))
+    n = int(rng.integers(2_000, 400_000))
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(500, 50_000)))
+    pieces = []
+    total = 0
+    while total < n:
+        L = int(rng.integers(1, 400))
+        st = int(rng.integers(0, max(1, len(genome) - L)))
+        r = bytearray(genome[st:st + L].tobytes())
+        if rng.random() < 0.3:
+            r = bytearray(bytes(r).lower())
+        for _ in range(int(rng.integers(0, 3))):
+            if len(r):
+                r[int(rng.integers(0, len(r)))] = int(rng.choice([0, 255, 10, 13, 32, ord("N"), ord("n"), ord(">"), ord("@"), ord("5"), ord("U")]))
+        pieces.append(bytes(r))
+        total += len(r) + 1
+    data = b"\n".join(pieces) + b"\n"
+    runs = [x for x in re.split(rb"[^ACGTacgt]+", data) if x]
+    for scale in (1, 16, 256, 4096):
+        sk = engine.Sketcher(k, s, m, expected_bytes=len(data), budget_scale=scale)
+        cut = int(rng.integers(0, len(pieces)))
+        first = b"\n".join(pieces[:cut]) + (b"\n" if cut else b"")
+        if first:
+            sk.push_host(first, engine.FMT_SEQ)
+        rest = data[len(first):]
+        if rest:
+            sk.push_host(rest, engine.FMT_SEQ)
+        try:
+            got_h, got_c = sk.finish()
+        except engine.EngineError as e:
+            sk.close()
+            if e.code != engine.MHX_E_CAPACITY:
+                raise
+            continue
+        sk.close()
+        break
+    want_h, want_c = mo.bruteforce_sketch(runs, k, s, m)
+    assert np.array_equal(got_h, want_h), (k, s, m, n)
+    assert np.array_equal(got_c, want_c)
+
+
+@pytest.mark.parametrize("seed", range(5 * FUZZ))
+def test_randomised_fasta_files(tmp_path, seed):
+    """FASTA mode (one reference per file): random record counts and lengths (some shorter than k), line
+    widths, lower case, IUPAC codes, blank lines between records, CRLF, plain or gzip; .msh bytes against
+    the oracle, then the distance table of the file against itself."""
+    import gzip
+
+    rng = np.random.default_rng(8500 + seed)
+    k = int(rng.choice([9, 16, 21, 27, 32]))
+    s = int(rng.choice([10, 1000, 50000]))
+    paths = []
+    for fi in range(int(rng.integers(1, 4))):
+        recs = []
+        for i in range(int(rng.integers(1, 30))):
+            L = int(rng.integers(1, 3000))
+            seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+            for _ in range(int(rng.integers(0, 4))):
+                seq[int(rng.integers(0, L))] = rng.choice(np.frombuffer(b"NRYKMSWBDHV", np.uint8))
+            seq = bytes(seq)
+            if rng.random() < 0.3:
+                seq = seq.lower()
+            w = int(rng.choice([50, 60, 70, 80, 1 << 30]))
+            body = b"\n".join(seq[j:j + w] for j in range(0, L, w))
+            hdr = b">c%d_%d" % (fi, i) + (b" len=%d some words" % L if rng.random() < 0.7 else b"")
+            recs.append(hdr + b"\n" + body + b"\n" + (b"\n" if rng.random() < 0.1 else b""))
+        data = b"".join(recs)
+        if rng.random() < 0.2:
+            data = data.replace(b"\n", b"\r\n")
+        if rng.random() < 0.2:
+            data = data.rstrip(b"\r\n")
+        p = tmp_path / ("g%d.fa" % fi)
+        if rng.random() < 0.5:
+            p = tmp_path / ("g%d.fa.gz" % fi)
+            with gzip.open(p, "wb", compresslevel=int(rng.integers(1, 10))) as fh:
+                fh.write(data)
+        else:
+            p.write_bytes(data)
+        paths.append(p)
+    try:
+        osk, _ = mo.sketch_files(paths, k, s)
+    except Exception as e:               # a file without any record of >= k bases: both sides must refuse it
+        with pytest.raises(engine.EngineError):
+            engine.sketch_files(paths, k, s, tmp_path / "e.msh")
+        return
+    engine.sketch_files(paths, k, s, tmp_path / "e.msh")
+    assert (tmp_path / "e.msh").read_bytes() == mo.msh_bytes(osk), (k, s)
+    assert engine.dist_files(tmp_path / "e.msh", tmp_path / "e.msh") == mo.dist_text(osk, osk)
