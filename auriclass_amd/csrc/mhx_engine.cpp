@@ -1174,9 +1174,9 @@ static int bulk_load_plain(const char *path, BulkFile *f)
     return rc;
 }
 
-// name / comment of the first record mash would count (sequence of at least k bytes); falls back to
-// the first header when none of the records in `buf` is long enough
-static void first_counted_header(const uint8_t *buf, size_t n, int k, std::string &name, std::string &comment)
+// name / comment of the first record mash would count (sequence of at least k bytes) in `buf`; false
+// when none of the records there is long enough (name / comment then hold the first header as a last resort)
+static bool first_counted_header(const uint8_t *buf, size_t n, int k, std::string &name, std::string &comment)
 {
     size_t p = 0;
     while (p < n) {
@@ -1186,7 +1186,7 @@ static void first_counted_header(const uint8_t *buf, size_t n, int k, std::strin
         const uint8_t *s_end = s0 < n ? (const uint8_t *)memchr(buf + s0, '\n', n - s0) : nullptr;
         const size_t s1 = s_end ? (size_t)(s_end - buf) : n;
         const size_t seq_len = s1 - s0 - ((s1 > s0 && buf[s1 - 1] == '\r') ? 1 : 0); // CRLF files: the CR is not a base
-        if (seq_len >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return; }
+        if (seq_len >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return true; }
         // skip the '+' and quality lines
         size_t q = s1 + 1;
         for (int i = 0; i < 2 && q < n; ++i) {
@@ -1196,7 +1196,28 @@ static void first_counted_header(const uint8_t *buf, size_t n, int k, std::strin
         p = q;
     }
     first_header(buf, n, name, comment);
+    return false;
 }
+
+// Which record names the reference: the first counted record of the lowest-numbered file that has one
+// (within its first chunk); the very first header if no file has any.
+struct HeaderPick {
+    int file = -1;        // file that provided a counted record
+    bool fallback = false;
+    std::string name, comment, fb_name, fb_comment;
+    void offer(int f, const uint8_t *buf, size_t n, int k)
+    {
+        if (file >= 0 && f > file) return;
+        std::string nm, cm;
+        if (first_counted_header(buf, n, k, nm, cm)) { file = f; name = nm; comment = cm; }
+        else if (!fallback || f == 0) { fallback = true; fb_name = nm; fb_comment = cm; }
+    }
+    void result(std::string &nm, std::string &cm) const
+    {
+        if (file >= 0) { nm = name; cm = comment; }
+        else { nm = fb_name; cm = fb_comment; }
+    }
+};
 } // namespace
 
 // returns MHX_OK with *handled = true when the streaming path produced the sketch;
@@ -1211,7 +1232,8 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     mhx_sketcher *sk = nullptr;
     int rc = mhx_sketcher_create(k, s, m, expected, &sk);
     if (rc) return rc;
-    bool fallback = false, have_header = false;
+    bool fallback = false;
+    HeaderPick header;
     // 1. uncompressed files: whole file -> one device buffer -> one push (see bulk_load_plain).  The buffers
     // stay on the device until the sketch is final, so that a too-small admission budget can be repaired by
     // pushing them again into a larger sketcher instead of reading the files a second time.
@@ -1225,10 +1247,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         if (rc) break;
         if (!bf.d_buf) { queued.push_back(i); continue; }
         if (bf.head.empty() || bf.head[0] != '@') fallback = true;
-        if (!fallback && (!have_header || i == 0)) {
-            first_counted_header(bf.head.data(), bf.head.size(), k, *fname, *fcomment);
-            have_header = true;
-        }
+        if (!fallback) header.offer(i, bf.head.data(), bf.head.size(), k);
         if (!fallback) rc = mhx_sketcher_push_device(sk, bf.d_buf, bf.size, MHX_FMT_FASTQ4);
         if (hipStreamSynchronize(g.stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "stream sync failed");
         bf.head.clear();
@@ -1247,10 +1266,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         IngestChunk c;
         while (q.get(c)) {
             if (rc) continue; // drain
-            if (c.first_of_file && (!have_header || c.file == 0)) {
-                first_counted_header(c.data(), std::min<size_t>(c.size, 1u << 20), k, *fname, *fcomment);
-                have_header = true;
-            }
+            if (c.first_of_file) header.offer(c.file, c.data(), std::min<size_t>(c.size, 1u << 20), k);
             if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
             rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
             if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
@@ -1294,6 +1310,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         uint64_t stt[8];
         rc = mhx_sketcher_stats(sk, stt);
         *kmers = stt[0];
+        header.result(*fname, *fcomment);
         if (!rc) rc = mhx_sketcher_record_count(sk, records); // sequences of >= k bytes, counted by the device parser
         hashes.resize(n);
         counts.resize(n);

@@ -549,8 +549,8 @@ def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
     cuts = sorted(set(int(x) for x in rng.integers(0, len(recs) + 1, n_push - 1))) if n_push > 1 else []
     bounds = [0] + cuts + [len(recs)]
     total = sum(len(r) for r in recs)
-    sk = engine.Sketcher(k, s, m, expected_bytes=total if rng.random() < 0.7 else 0)
-    keep = []
+    expected = total if rng.random() < 0.7 else 0
+    spans = []
     for a, b in zip(bounds[:-1], bounds[1:]):
         blob = b"".join(recs[a:b])
         if not blob:
@@ -558,12 +558,22 @@ def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
         lead = int(rng.integers(0, 40))
         dev = torch.zeros(len(blob) + lead + 64, dtype=torch.uint8, device="cuda")
         dev[lead:lead + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
-        torch.cuda.synchronize()
-        keep.append(dev)
-        sk.push_device(dev.data_ptr() + lead, len(blob), engine.FMT_FASTQ4)
-    got, got_c = sk.finish()
-    n_long = sk.record_count()
-    sk.close()
+        spans.append((dev, lead, len(blob)))
+    torch.cuda.synchronize()
+    for scale in (1, 16, 256, 4096):     # MHX_E_CAPACITY: fewer than s solid k-mers, repeat with a larger budget
+        sk = engine.Sketcher(k, s, m, expected_bytes=expected, budget_scale=scale)
+        for dev, lead, n in spans:
+            sk.push_device(dev.data_ptr() + lead, n, engine.FMT_FASTQ4)
+        try:
+            got, got_c = sk.finish()
+        except engine.EngineError as e:
+            sk.close()
+            if e.code != engine.MHX_E_CAPACITY:
+                raise
+            continue
+        n_long = sk.record_count()
+        sk.close()
+        break
     ref = mo.Sketcher(k, s, m)
     ref.add_fastx(b"".join(recs))
     want, want_c = ref.finish()
@@ -809,3 +819,21 @@ def test_randomised_fasta_files(tmp_path, seed):
     engine.sketch_files(paths, k, s, tmp_path / "e.msh")
     assert (tmp_path / "e.msh").read_bytes() == mo.msh_bytes(osk), (k, s)
     assert engine.dist_files(tmp_path / "e.msh", tmp_path / "e.msh") == mo.dist_text(osk, osk)
+
+
+def test_reference_is_named_after_the_first_counted_record_across_files(tmp_path):
+    """When every record of the first file is shorter than k, mash's comment names the first record of the
+    next file that has a long enough one (the count skips the short ones too)."""
+    genome = synth.make_genome(30_000, seed=61)
+    short = synth.make_fastq(genome, 500, 20, seed=62, device="cpu").numpy().tobytes()
+    longer = synth.make_fastq(genome, 800, 90, seed=63, device="cpu", first_index=7000).numpy().tobytes()
+    a, b = tmp_path / "a.fq", tmp_path / "b.fq"
+    a.write_bytes(short)
+    b.write_bytes(longer)
+    engine.sketch_files([a, b], 27, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
+    ref = mo.Sketcher(27, 1000, 1)
+    ref.add_fastx(short)
+    ref.add_fastx(longer)
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert got.comment == ref.comment() == "[800 seqs] r00007000  [...]"
+    assert np.array_equal(got.hashes, ref.finish()[0])
