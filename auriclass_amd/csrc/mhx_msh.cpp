@@ -289,6 +289,9 @@ int msh_read_file(const char *path, SketchSet &s)
                     r.hashes.resize(n);
                     for (uint32_t j = 0; j < n; ++j) r.hashes[j] = p32[j];
                 }
+                // the distance kernels merge ascending duplicate-free lists (what mash writes); anything else is a damaged file
+                for (size_t j = 1; j < r.hashes.size(); ++j)
+                    if (r.hashes[j] <= r.hashes[j - 1]) return fail(MHX_E_FORMAT, "%s: hash list of reference %u is not ascending", path, i);
                 if (ep > 6) {
                     Reader::Target c = rd.resolve(lst.seg, pp + 6);
                     if (c.ok && (c.hi & 7) == 4) {

@@ -151,7 +151,7 @@ def _text_call(fn, *args) -> str:
     _check(fn(*args, None, 0, ctypes.byref(need)))
     buf = ctypes.create_string_buffer(need.value)
     _check(fn(*args, buf, need.value, ctypes.byref(need)))
-    return buf.value.decode("utf-8")
+    return buf.value.decode("utf-8", "surrogateescape")   # names inside a .msh are arbitrary bytes
 
 
 # --------------------------------------------------------------------------- file level
@@ -169,7 +169,7 @@ def sketch_files(paths: Sequence, k: int, s: int, out_msh, reads: bool = False, 
     if rc == MHX_E_NO_RECORDS:
         raise NoRecordsError(rc, L.mhx_last_error().decode())
     _check(rc)
-    return buf.value.decode("utf-8"), est.value
+    return buf.value.decode("utf-8", "surrogateescape"), est.value
 
 
 def dist_files(ref_msh, qry_msh) -> str:
