@@ -585,27 +585,33 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
 }
 
 static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
-{ // LSD radix sort on the 64-bit keys (8 passes of 8 bits, passes with a constant byte skipped)
+{ // The extracted hashes are (close to) uniform below the threshold: one scatter into n buckets by value, then an
+  // insertion sort over the almost-sorted result (O(n) expected; any input still ends up sorted).
     const size_t n = keys.size();
     if (n < 2) return;
+    uint64_t hi = 0;
+    for (size_t i = 0; i < n; ++i) hi = keys[i] > hi ? keys[i] : hi;
+    std::vector<uint32_t> start(n + 1, 0);
+    auto bucket = [&](uint64_t k) { return (size_t)(((unsigned __int128)k * n) / ((unsigned __int128)hi + 1)); };
+    for (size_t i = 0; i < n; ++i) ++start[bucket(keys[i]) + 1];
+    for (size_t b = 0; b < n; ++b) start[b + 1] += start[b];
     std::vector<uint64_t> k2(n);
     std::vector<uint32_t> c2(n);
-    for (int pass = 0; pass < 8; ++pass) {
-        const int sh = 8 * pass;
-        size_t hist[257] = {0};
-        for (size_t i = 0; i < n; ++i) ++hist[((keys[i] >> sh) & 0xFF) + 1];
-        bool trivial = false;
-        for (int b = 1; b <= 256; ++b) if (hist[b] == n) trivial = true;
-        if (trivial) continue;
-        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
-        for (size_t i = 0; i < n; ++i) {
-            const size_t d = hist[(keys[i] >> sh) & 0xFF]++;
-            k2[d] = keys[i];
-            c2[d] = cnts[i];
-        }
-        keys.swap(k2);
-        cnts.swap(c2);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t d = start[bucket(keys[i])]++;
+        k2[d] = keys[i];
+        c2[d] = cnts[i];
     }
+    for (size_t i = 1; i < n; ++i) {
+        const uint64_t k = k2[i];
+        const uint32_t c = c2[i];
+        size_t j = i;
+        while (j > 0 && k2[j - 1] > k) { k2[j] = k2[j - 1]; c2[j] = c2[j - 1]; --j; }
+        k2[j] = k;
+        c2[j] = c;
+    }
+    keys.swap(k2);
+    cnts.swap(c2);
 }
 
 static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
