@@ -133,3 +133,47 @@ def test_argument_logic_and_parser():
     with pytest.raises(SystemExit):
         p.parse_args(["x.fq", "-k", "40"])
     assert general.add_tag("t", "a\n\nb") == "[t] a\n[t] b" and general.add_tag("t", "") == "[t]"
+
+
+# ---- 84 scenarios whose expectations were produced by the reference's own Python layer ----------------
+def _scenarios():
+    import json
+
+    return json.loads((GOLDEN / "report_scenarios.json").read_text())
+
+
+@pytest.mark.parametrize("sc", _scenarios(), ids=lambda sc: "%s-%d" % (sc["mode"], sc["id"]))
+def test_report_scenarios_from_the_reference(tmp_path, monkeypatch, sc):
+    """tests/golden/report_scenarios.json: random dist tables over 24 references in 6 clades (clear hits,
+    second hits inside the error bound, outgroup hits, ties, nothing close), genome sizes around the
+    expected range, thresholds, --no_qc, and the two quirks of the bounds lookup.  The expected report
+    rows / exception types come from /root/reference/auriclass/classes.py itself
+    (tests/golden/make_report_scenarios.py); here the same texts go through the mirror."""
+    bounds = (GOLDEN / "mash_bounds_k27_p0.99.txt").read_text()
+    est = sc["estimated_genome_size"]
+    monkeypatch.setattr(engine, "sketch_files", lambda paths, k, s, out, reads=False, min_mult=1: (
+        ("Estimated genome size: %g\nEstimated coverage:    40\n" % est) if reads else "Sketching x...\n", est))
+    monkeypatch.setattr(engine, "dist_files", lambda r, q: sc["dist_text"])
+    monkeypatch.setattr(engine, "bounds", lambda k, p: bounds)
+    monkeypatch.setattr(engine, "fasta_total_bases", lambda p: int(est))
+    clade_csv = tmp_path / "clades.csv"
+    clade_csv.write_text("filename,clade\n" + "".join("%s,%s\n" % kv for kv in sc["clades"].items()))
+    cls = classes.FastqAuriclass if sc["mode"] == "fastq" else classes.FastaAuriclass
+    report = tmp_path / "report.tsv"
+    obj = cls(name="isolate", output_report_path=report,
+              read_paths=["reads_1.fq.gz", "reads_2.fq.gz"] if sc["mode"] == "fastq" else ["asm.fasta"],
+              reference_sketch_path="refs.msh", kmer_size=27, sketch_size=sc["sketch_size"], minimal_kmer_coverage=3,
+              clade_config_path=clade_csv, genome_size_range=sc["genome_size_range"],
+              non_candida_threshold=sc["non_candida_threshold"], high_dist_threshold=sc["high_dist_threshold"], no_qc=sc["no_qc"])
+    want = sc["expect"]
+    if "raises" in want:
+        with pytest.raises(Exception) as ei:
+            obj.run()
+        assert type(ei.value).__name__ == want["raises"]
+        return
+    obj.run()
+    assert report.read_text() == want["report"]
+    assert obj.clade == want["clade"]
+    assert float(obj.minimal_distance) == want["minimal_distance"]
+    assert int(obj.samples_within_error_bound) == want["samples_within_error_bound"]
+    assert float(obj.error_bound) == want["error_bound"]
