@@ -177,3 +177,51 @@ def test_report_scenarios_from_the_reference(tmp_path, monkeypatch, sc):
     assert float(obj.minimal_distance) == want["minimal_distance"]
     assert int(obj.samples_within_error_bound) == want["samples_within_error_bound"]
     assert float(obj.error_bound) == want["error_bound"]
+
+
+# ---- small helpers: vectors produced by the reference's general.py / args.py -----------------------------
+def _helper_goldens():
+    import json
+
+    return json.loads((GOLDEN / "helper_goldens.json").read_text())
+
+
+def _outcome(fn):
+    try:
+        return {"value": fn()}
+    except SystemExit as e:
+        return {"raises": "SystemExit", "code": e.code}
+    except BaseException as e:
+        return {"raises": type(e).__name__}
+
+
+def test_helper_functions_match_the_reference_vectors(capsys):
+    """tests/golden/helper_goldens.json (made by tests/golden/make_helper_goldens.py from the reference):
+    add_tag, the argparse range validators (they return str, not numbers), the genome-size logic (Mbp below
+    100, lower > upper) and the parsed namespace of eleven argument vectors, errors included."""
+    from pathlib import Path
+
+    from auriclass_amd.args import auriclass_arg_parser
+
+    g = _helper_goldens()
+    for c in g["add_tag"]:
+        assert general.add_tag(c["tag"], c["lines"]) == c["out"]
+    for c in g["range"]:
+        got = _outcome(lambda: general.check_number_within_range(c["min"], c["max"])(c["value"]))
+        assert got == {k: v for k, v in c.items() if k in ("value", "raises") and not (k == "value" and "raises" in c)} or \
+            got == ({"raises": c["raises"]} if "raises" in c else {"value": c["value"]}), c
+    for c in g["logic"]:
+        ns = argparse.Namespace(expected_genome_size=list(c["pair"]))
+        got = _outcome(lambda: general.validate_argument_logic(ns).expected_genome_size)
+        want = {"raises": c["raises"]} if "raises" in c else {"value": c["value"]}
+        assert got == want, c
+    skip = {"clade_config_path", "reference_sketch_path"}       # defaults depend on where the package is installed
+    for c in g["argv"]:
+        def parse():
+            ns = auriclass_arg_parser(c["argv"])
+            return {k: (str(v) if isinstance(v, Path) else v) for k, v in sorted(vars(ns).items()) if k not in skip}
+        got = _outcome(parse)
+        if "raises" in c:
+            assert got.get("raises") == c["raises"] and got.get("code") == c.get("code"), c
+        else:
+            assert got == {"value": {k: v for k, v in c["value"].items() if k not in skip}}, c
