@@ -50,8 +50,9 @@ struct DistArgs {
     const uint32_t *r_len;
     uint32_t nq, nr, stride, s;
     int k;
-    uint32_t *common, *denom;
+    uint32_t *common, *denom; // [nq][out_stride], this call fills columns out_off .. out_off + nr - 1
     double *dist;
+    uint32_t out_stride, out_off;
 };
 hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st);
 

@@ -754,7 +754,7 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
     const uint64_t pairs = (uint64_t)nq * nr;
     if (pairs > 0x7FFFFFFFull) return fail(MHX_E_ARG, "too many pairs for one call");
     DistArgs a;
-    a.nq = nq; a.nr = nr; a.stride = stride; a.s = s; a.k = k;
+    a.nq = nq; a.nr = nr; a.stride = stride; a.s = s; a.k = k; a.out_stride = nr; a.out_off = 0;
     void *dq = nullptr, *dr = nullptr, *dql = nullptr, *drl = nullptr, *dc = nullptr, *dd = nullptr, *dx = nullptr;
     auto cleanup = [&]() { hipFree(dq); hipFree(dr); hipFree(dql); hipFree(drl); hipFree(dc); hipFree(dd); hipFree(dx); };
     if (device_ptrs) {
@@ -775,13 +775,14 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         a.q = (const uint64_t *)dq; a.q_len = (const uint32_t *)dql; a.r = (const uint64_t *)dr; a.r_len = (const uint32_t *)drl;
         a.common = (uint32_t *)dc; a.denom = (uint32_t *)dd; a.dist = nullptr; // distances in host libm below
     }
-    // all-vs-refs fast path when the reference set fits one 32-bit mask; the generic
-    // pair-per-workgroup kernel otherwise, and as the fallback for non-uniform value ranges
-    const bool fast = nr <= 32 && pairs >= 64 && getenv("MHX_DIST_GENERIC") == nullptr;
+    // all-vs-refs fast path: the references go through in slices of 32 (one bit each in the range kernel's
+    // masks), every slice filling its columns of the [nq][nr] outputs; the generic pair-per-workgroup kernel
+    // serves tiny batches and is the fallback of a slice whose value ranges are too uneven for the LDS table
+    const bool fast = pairs >= 64 && getenv("MHX_DIST_GENERIC") == nullptr;
     DistWork w{};
     if (fast) {
         size_t oq, orr, oc, op;
-        const size_t need = dist_work_bytes(nq, nr, &oq, &orr, &oc, &op);
+        const size_t need = dist_work_bytes(nq, nr < 32 ? nr : 32, &oq, &orr, &oc, &op);
         if (g.dist_ws_cap < need) {
             hipFree(g.dist_ws);
             g.dist_ws = nullptr;
@@ -793,12 +794,20 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         w.cpart = (uint16_t *)(g.dist_ws + oc); w.params = (uint32_t *)(g.dist_ws + op);
     }
     hipEventRecord(g.ev0, g.stream);
-    hipError_t le = fast ? launch_dist_ranges(a, w, g.stream) : launch_dist_pairs(a, g.stream);
-    if (le == hipSuccess && fast) {
+    hipError_t le = hipSuccess;
+    if (!fast) le = launch_dist_pairs(a, g.stream);
+    for (uint32_t r0 = 0; fast && r0 < nr && le == hipSuccess; r0 += 32) {
+        DistArgs slice = a;
+        slice.r = a.r + (uint64_t)r0 * stride;
+        slice.r_len = a.r_len + r0;
+        slice.nr = nr - r0 < 32 ? nr - r0 : 32;
+        slice.out_off = r0;
+        le = launch_dist_ranges(slice, w, g.stream);
+        if (le != hipSuccess) break;
         uint32_t flag = 0;
         hipMemcpyAsync(&flag, w.params + 1, 4, hipMemcpyDeviceToHost, g.stream);
         hipStreamSynchronize(g.stream);
-        if (flag) le = launch_dist_pairs(a, g.stream); // a value range overflowed the LDS table
+        if (flag) le = launch_dist_pairs(slice, g.stream); // a value range overflowed the LDS table
     }
     hipEventRecord(g.ev1, g.stream);
     if (le != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le)); }

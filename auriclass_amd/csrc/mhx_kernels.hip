@@ -501,8 +501,9 @@ __global__ __launch_bounds__(256) void dist_pairs_kernel(const DistArgs a)
         const uint32_t uni = total - all;
         const uint32_t denom = uni < a.s ? uni : a.s;
         const uint32_t common = total_common;
-        a.common[pair] = common;
-        a.denom[pair] = denom;
+        const uint64_t out = (uint64_t)qi * a.out_stride + a.out_off + ri; // the references may be a slice of a wider batch
+        a.common[out] = common;
+        a.denom[out] = denom;
         if (a.dist) {
             double d;
             if (common == denom) d = 0.0;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void dist_pairs_kernel(const DistArgs a)
                 d = -log(2.0 * jac / (1.0 + jac)) / (double)a.k;
                 if (d > 1.0) d = 1.0;
             }
-            a.dist[pair] = d;
+            a.dist[out] = d;
         }
     }
 }
@@ -749,8 +750,9 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
         }
         denom = S; // this range holds enough further union elements by construction
     }
-    a.common[pair] = common;
-    a.denom[pair] = denom;
+    const uint64_t out = (uint64_t)q * a.out_stride + a.out_off + r; // the references may be a slice of a wider batch
+    a.common[out] = common;
+    a.denom[out] = denom;
     if (a.dist) {
         double d;
         if (common == denom) d = 0.0;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
             d = -log(2.0 * jac / (1.0 + jac)) / (double)a.k;
             if (d > 1.0) d = 1.0;
         }
-        a.dist[pair] = d;
+        a.dist[out] = d;
     }
 }
 
