@@ -361,6 +361,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     a.tile_state = sk->d_tile_state;
     TableArgs ta = table_args(sk);
     if (sk->nslots >= (1ull << 23) && !getenv("MHX_EXACT_TIGHTEN")) ta.sample = 8; // big tables: sampled passes between chunks (finish() counts exactly)
+    const uint64_t pushed_before = sk->bytes_pushed;
     uint32_t tile = 0;
     int launch = 0;
     while (tile < ntiles) {
@@ -389,7 +390,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             // the retry with a 16x budget.
             // No cap while the input looks like a small genome sequenced deeply (a fifth of the table entries
             // are solid already, yet fewer than s of them): its sketch may need every solid hash there is.
-            const uint64_t after = sk->bytes_pushed + (uint64_t)take * kTileBytes;
+            const uint64_t after = pushed_before + std::min<uint64_t>(n, (uint64_t)(tile + take) * kTileBytes);
             const bool saturating = sk->occupied > 0 && sk->solid * 5 >= sk->occupied;
             if (after > kUncappedBytes && !saturating) {
                 const long double s_eff = (long double)sk->s + 8.0L * sqrtl((long double)sk->s) + 16.0L;
@@ -419,7 +420,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         ++sk->launches;
         ++launch;
         tile += take;
-        sk->bytes_pushed += (uint64_t)take * kTileBytes;
+        sk->bytes_pushed = pushed_before + std::min<uint64_t>(n, (uint64_t)tile * kTileBytes); // real bytes, not whole tiles: callers may push tiny spans
         if (!sk->settled) {
             // tighten T from what has been seen, then decide whether the rest can go at once:
             // expected admissions of everything still to come must fit an eighth of the table

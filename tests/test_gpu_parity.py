@@ -837,3 +837,22 @@ def test_reference_is_named_after_the_first_counted_record_across_files(tmp_path
     got = mo.read_msh(tmp_path / "o.msh").references[0]
     assert got.comment == ref.comment() == "[800 seqs] r00007000  [...]"
     assert np.array_equal(got.hashes, ref.finish()[0])
+
+
+def test_thousands_of_tiny_pushes_with_multiplicity_filter():
+    """One read per push (300-byte spans, each its own launch): the stage accounting of the capped phase
+    must follow the real bytes, not whole tiles."""
+    import torch
+
+    genome = synth.make_genome(20_000, seed=71)
+    fq = synth.make_fastq(genome, 4000, 150, seed=72, device="cuda")
+    torch.cuda.synchronize()
+    rb = synth.record_bytes(150)
+    sk = engine.Sketcher(21, 2000, 3, expected_bytes=0)
+    for i in range(4000):
+        sk.push_device(fq.data_ptr() + i * rb, rb, engine.FMT_FASTQ4)
+    got, _ = sk.finish()
+    sk.close()
+    ref = mo.Sketcher(21, 2000, 3)
+    ref.add_fastx(fq.cpu().numpy().tobytes())
+    assert np.array_equal(got, ref.finish()[0])
