@@ -132,3 +132,34 @@ def test_mash_named_shim_serves_the_references_subprocess_calls(refcwd):
     assert "ERROR: Did not find fasta records in" in empty.stderr.decode() and empty.returncode == 1
     fa = mash("sketch", "-o", "ref2", "-k", "27", "-s", "50000", "tests/data/NC_001416.1.fasta", "tests/data/NC_001604.1.fasta")
     assert fa.returncode == 0 and open("ref2.msh", "rb").read() == (REFDATA / "ref_sketch.msh").read_bytes()
+
+
+def test_the_binding_stub_printed_in_INTEGRATION_md_works_as_written(refcwd, monkeypatch):
+    """INTEGRATION.md shows the ~40-line ctypes module a maintainer would drop next to the reference's
+    classes.py; the code block is executed verbatim here and driven with the argv lists of the five
+    call sites (classes.py:92-97, 305-312, 576-589, 696-706; general.py:198-205)."""
+    import re
+    from pathlib import Path
+
+    import auriclass_amd
+
+    root = Path(auriclass_amd.__file__).resolve().parent.parent
+    text = (root / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    monkeypatch.setenv("MHX_LIB", str(root / "auriclass_amd" / "lib" / "libmhx.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    run = ns["run"]
+    assert run(["mash", "-h"]).stdout == b""
+    out = run(["mash", "sketch", "-r", "-m", "3", "-o", "stub_q.msh", "-k", "27", "-s", "50000",
+               "tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz"])
+    assert b"Estimated genome size: 48454.7" in out.stderr
+    rows = run(["mash", "dist", "tests/data/ref_sketch.msh", "stub_q.msh"]).stdout.decode()
+    assert rows == ("tests/data/NC_001416.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t9.55405e-06\t0\t48451/48476\n"
+                    "tests/data/NC_001604.1.fasta\ttests/data/NC_001416.1_1.fq.gz\t1\t1\t0/50000\n")
+    assert run(["mash", "bounds", "-k", "27", "-p", "0.99"]).stdout.decode() == (GOLDEN / "mash_bounds_k27_p0.99.txt").read_text()
+    fa = run(["mash", "sketch", "-o", "stub_ref.msh", "-k", "27", "-s", "50000", "tests/data/NC_001416.1.fasta", "tests/data/NC_001604.1.fasta"])
+    assert b"Sketching tests/data/NC_001416.1.fasta..." in fa.stderr
+    assert open("stub_ref.msh", "rb").read() == (REFDATA / "ref_sketch.msh").read_bytes()
+    empty = run(["mash", "sketch", "-r", "-m", "3", "-o", "stub_e.msh", "-k", "27", "-s", "50000", "tests/data/test_empty_1.fq.gz"])
+    assert b"ERROR: Did not find fasta records in" in empty.stderr
