@@ -1,35 +1,24 @@
 // mhx_engine.cpp -- host side of libmhx: device selection, the sketcher object that
-// schedules tile launches and threshold tightening, the batched distance entry point and
-// the two file-level calls that replace AuriClass's `mash sketch` / `mash dist`
-// subprocesses (/root/reference/auriclass/classes.py:576-596, 696-713, 92-104).
+// schedules tile launches and threshold tightening, the multi-GPU partial export and the
+// batched distance entry point.  The file-level calls that replace AuriClass's
+// `mash sketch` / `mash dist` subprocesses live in mhx_files.cpp.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <fcntl.h>
-#include <sys/stat.h>
-#include <unistd.h>
 
-#include <zlib.h>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 #include <algorithm>
-#include <chrono>
 #include <exception>
 #include <new>
-#include <condition_variable>
-#include <deque>
 #include <memory>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "mhx_device.h"
+#include "mhx_engine_internal.h"
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -48,31 +37,9 @@ int fail(int code, const char *fmt, ...)
 }
 void clear_error() { g_err.clear(); }
 
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(MHX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+Engine g;
 
-// ---- engine state ---------------------------------------------------------------------
-struct Engine {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
-    bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_dist_ms = 0.0;
-    uint8_t *dist_ws = nullptr; // workspace of the all-vs-refs distance path
-    size_t dist_ws_cap = 0;
-    // bulk file ingest: pinned staging ring + copy stream (allocated on first use, kept)
-    static constexpr int kPinnedSlots = 4;
-    uint8_t *pinned[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pinned_free[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
-};
-static Engine g;
-
-static int require_engine()
+int require_engine()
 {
     if (!g.ready) return fail(MHX_E_NO_DEVICE, "mhx: no GPU engine (call mhx_init on a machine with a HIP device; there is no CPU fallback)");
     return MHX_OK;
@@ -247,7 +214,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     return MHX_OK;
 }
 
-static int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint64_t table_scale, mhx_sketcher **out)
+int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint64_t table_scale, mhx_sketcher **out)
 {
     clear_error();
     int rc = require_engine();
@@ -841,737 +808,6 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         }
     }
     return MHX_OK;
-}
-
-// ---- file level -------------------------------------------------------------------------
-static int put_text(const std::string &t, char *buf, size_t cap, size_t *need)
-{
-    if (need) *need = t.size() + 1;
-    if (cap == 0) return MHX_OK;
-    if (!buf || cap < t.size() + 1) return fail(MHX_E_CAPACITY, "text buffer too small (%zu needed)", t.size() + 1);
-    memcpy(buf, t.c_str(), t.size() + 1);
-    return MHX_OK;
-}
-
-static std::string make_comment(const std::string &name, const std::string &comment, uint64_t count)
-{ // mash sketchFile(): "<name> <comment>", wrapped when several records were counted
-    std::string c = name + " " + comment;
-    if (count > 1) c = "[" + std::to_string(count) + " seqs] " + c + " [...]";
-    return c;
-}
-
-struct Loaded {
-    std::vector<uint8_t> raw;  // inflated file
-    ParsedRecords rec;         // filled when the record parser path is used
-    bool fastq4 = false;
-};
-
-// One reference from one or more inputs on the device.  On a 4-line violation or a too
-// tight admission bound the whole reference is redone (record parser / bigger table).
-static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t s, uint32_t m, bool allow_device_fastq,
-                            std::vector<uint64_t> &hashes, std::vector<uint32_t> &counts, uint64_t *kmers)
-{
-    uint64_t total = 0;
-    for (auto *in : inputs) total += in->raw.size();
-    bool device_fastq = allow_device_fastq;
-    uint64_t boost = 1;
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        mhx_sketcher *sk = nullptr;
-        int rc = create_sketcher(k, s, m, total, boost, &sk);
-        if (rc) return rc;
-        for (auto *in : inputs) {
-            if (device_fastq && in->fastq4) {
-                rc = mhx_sketcher_push_host(sk, in->raw.data(), in->raw.size(), MHX_FMT_FASTQ4);
-            } else {
-                if (in->rec.records_seen == 0 && in->rec.seq.empty()) {
-                    rc = parse_fastx(in->raw.data(), in->raw.size(), k, in->rec);
-                    if (rc) break;
-                }
-                rc = mhx_sketcher_push_host(sk, in->rec.seq.data(), in->rec.seq.size(), MHX_FMT_SEQ);
-            }
-            if (rc) break;
-        }
-        uint32_t n = 0;
-        if (!rc) {
-            hashes.resize(s);
-            counts.resize(s);
-            rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
-        }
-        if (!rc && kmers) {
-            uint64_t st[8];
-            rc = mhx_sketcher_stats(sk, st);
-            *kmers = st[0];
-        }
-        mhx_sketcher_destroy(sk);
-        if (rc == MHX_E_FORMAT && device_fastq) { device_fastq = false; continue; }
-        if (rc == MHX_E_CAPACITY) { boost *= 16; continue; }
-        if (rc) return rc;
-        hashes.resize(n);
-        counts.resize(n);
-        return MHX_OK;
-    }
-    return fail(MHX_E_CAPACITY, "could not size the device table for this input");
-}
-
-// ---- streaming FASTQ ingest ---------------------------------------------------------------
-// Reads mode on real inputs is inflate-bound (zlib, ~0.1-0.3 GB/s per stream), so every input
-// file gets its own inflate thread; each thread cuts its stream into <= 32 MiB chunks at record
-// boundaries (a multiple of four lines since the start of the file) and hands them to the
-// caller's thread, which copies them to the device and pushes them through the FASTQ kernel
-// while the other files keep inflating.  Host memory stays bounded (a few chunks per file).
-namespace {
-constexpr size_t kIngestChunk = 32u << 20;
-
-// One record-aligned piece of an inflated FASTQ.  The buffer keeps GzInflater::kWindow bytes of room in
-// front of the data: the previous 32 KiB of the stream, which DEFLATE matches may still refer to.
-struct IngestChunk {
-    std::unique_ptr<uint8_t[]> buf; // kWindow + kIngestChunk + slack bytes, not zero-filled
-    size_t size = 0;
-    int file = 0;
-    bool first_of_file = false;
-    uint8_t *data() { return buf.get() + GzInflater::kWindow; }
-    static size_t alloc_bytes() { return GzInflater::kWindow + kIngestChunk + GzInflater::kOvershoot + 64; }
-};
-
-class ChunkQueue {
-  public:
-    void put(IngestChunk &&c)
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        room_.wait(lk, [&] { return q_.size() < 4 || abort_; });
-        if (abort_) return;
-        q_.push_back(std::move(c));
-        ready_.notify_one();
-    }
-    bool get(IngestChunk &out) // false when every producer is done and the queue is empty
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        ready_.wait(lk, [&] { return !q_.empty() || live_ == 0; });
-        if (q_.empty()) return false;
-        out = std::move(q_.front());
-        q_.pop_front();
-        room_.notify_one();
-        return true;
-    }
-    // chunk buffers go round: fresh 32 MiB allocations cost more in page faults than the inflate that fills them
-    std::unique_ptr<uint8_t[]> take_buffer()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (!spare_.empty()) { std::unique_ptr<uint8_t[]> b = std::move(spare_.back()); spare_.pop_back(); return b; }
-        }
-        return std::unique_ptr<uint8_t[]>(new uint8_t[IngestChunk::alloc_bytes()]);
-    }
-    void give_back(std::unique_ptr<uint8_t[]> b) { if (b) { std::lock_guard<std::mutex> lk(m_); spare_.push_back(std::move(b)); } }
-    void producer_started() { std::lock_guard<std::mutex> lk(m_); ++live_; }
-    void producer_done() { std::lock_guard<std::mutex> lk(m_); --live_; ready_.notify_all(); }
-    void abort() { std::lock_guard<std::mutex> lk(m_); abort_ = true; room_.notify_all(); }
-    bool aborted() { std::lock_guard<std::mutex> lk(m_); return abort_; }
-
-  private:
-    std::mutex m_;
-    std::condition_variable ready_, room_;
-    std::deque<IngestChunk> q_;
-    std::vector<std::unique_ptr<uint8_t[]>> spare_;
-    int live_ = 0;
-    bool abort_ = false;
-};
-
-struct FileIngestState {
-    std::string error;
-    uint64_t lines = 0, bytes = 0;
-    bool not_fastq4 = false;
-    bool own_inflate_failed = false; // the engine's own DEFLATE decoder refused the stream
-};
-
-static bool is_gzip_file(const char *path)
-{
-    FILE *f = fopen(path, "rb");
-    uint8_t magic[2] = {0, 0};
-    if (f) { if (fread(magic, 1, 2, f) != 2) magic[0] = 0; fclose(f); }
-    return magic[0] == 0x1f && magic[1] == 0x8b;
-}
-
-#if defined(__x86_64__)
-__attribute__((target("avx2,popcnt"))) static size_t count_newlines_avx2(const uint8_t *p, size_t n)
-{
-    const __m256i nl = _mm256_set1_epi8('\n');
-    size_t c = 0, i = 0;
-    for (; i + 128 <= n; i += 128) {
-        const uint32_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl));
-        const uint32_t m1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 32)), nl));
-        const uint32_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 64)), nl));
-        const uint32_t m3 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 96)), nl));
-        c += (size_t)__builtin_popcountll(((uint64_t)m1 << 32) | m0) + (size_t)__builtin_popcountll(((uint64_t)m3 << 32) | m2);
-    }
-    for (; i < n; ++i) c += p[i] == '\n';
-    return c;
-}
-#endif
-
-static size_t count_newlines(const uint8_t *p, size_t n)
-{
-#if defined(__x86_64__)
-    static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
-    if (avx2) return count_newlines_avx2(p, n);
-#endif
-    size_t c = 0;
-    for (size_t i = 0; i < n; ++i) c += p[i] == '\n';
-    return c;
-}
-
-static bool read_whole_file(const char *path, std::vector<uint8_t> &out, size_t pad)
-{
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    struct stat sb;
-    if (fstat(fileno(f), &sb) != 0) { fclose(f); return false; }
-    out.assign((size_t)sb.st_size + pad, 0);
-    const size_t got = fread(out.data(), 1, (size_t)sb.st_size, f);
-    fclose(f);
-    return got == (size_t)sb.st_size;
-}
-
-// Producer of one input file: inflates it (own DEFLATE decoder on the whole compressed file in memory;
-// MHX_ZLIB_INFLATE=1 selects zlib's gzread instead; an uncompressed file is simply read) and cuts the
-// stream into record-aligned chunks.
-void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, FileIngestState *st)
-{
-    const bool gz = is_gzip_file(path);
-    const bool own = gz && !force_zlib && !getenv("MHX_ZLIB_INFLATE");
-    gzFile g = nullptr;
-    FILE *plain = nullptr;
-    std::vector<uint8_t> zbytes;
-    GzInflater inf;
-    if (own) {
-        if (!read_whole_file(path, zbytes, 16)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
-        inf.set_input(zbytes.data(), zbytes.size() - 16);
-    } else if (gz) {
-        g = gzopen(path, "rb");
-        if (g) gzbuffer(g, 1 << 20);
-    } else {
-        plain = fopen(path, "rb");
-    }
-    if (!own && !g && !plain) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
-    auto close_all = [&]() { if (g) gzclose(g); if (plain) fclose(plain); };
-    std::vector<uint8_t> tail; // [history in front of the carry][carry]: the end of the previous chunk's stream
-    size_t carry_len = 0;
-    uint64_t produced = 0;     // inflated bytes so far (bounds how far back a match may reach)
-    bool first = true;
-    uint64_t lines_before = 0; // newlines in everything already emitted
-    const bool dbg = getenv("MHX_INGEST_DEBUG") != nullptr;
-    double t_alloc = 0, t_inflate = 0, t_cut = 0, t_put = 0;
-    auto now = []() { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    struct Report { bool on; const char *path; double *a, *i, *c, *p; ~Report() { if (on) fprintf(stderr, "ingest %s: alloc %.3f inflate %.3f cut %.3f put-wait %.3f s\n", path, *a, *i, *c, *p); } } report{dbg, path, &t_alloc, &t_inflate, &t_cut, &t_put};
-    for (;;) {
-        auto t0 = now();
-        IngestChunk c;
-        c.file = file;
-        c.first_of_file = first;
-        c.buf = q->take_buffer();
-        uint8_t *d = c.data();
-        if (!tail.empty()) memcpy(d + carry_len - tail.size(), tail.data(), tail.size());
-        t_alloc += secs(t0, now());
-        t0 = now();
-        size_t n = carry_len;
-        bool eof = false;
-        while (n < kIngestChunk) {
-            long got;
-            if (own) {
-                const uint64_t hist = produced < GzInflater::kWindow ? produced : GzInflater::kWindow;
-                const size_t r = inf.inflate(d + n, kIngestChunk - n, d + n - hist);
-                if (r == (size_t)-1) got = -1;
-                else { got = (long)r; produced += r; if (inf.done()) { n += r; eof = true; break; } }
-            } else if (gz) {
-                got = gzread(g, d + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
-            } else {
-                got = (long)fread(d + n, 1, kIngestChunk - n, plain);
-                if (got == 0 && ferror(plain)) got = -1;
-            }
-            if (got < 0) {
-                st->error = std::string("ERROR: reading ") + path + " failed";
-                st->own_inflate_failed = own; // the caller repeats the run with zlib before giving up
-                close_all();
-                q->producer_done();
-                return;
-            }
-            if (got == 0) { eof = true; break; }
-            n += (size_t)got;
-        }
-        t_inflate += secs(t0, now());
-        t0 = now();
-        if (first && n && d[0] != '@') { st->not_fastq4 = true; close_all(); q->producer_done(); return; }
-        // cut after the last newline that completes a record (line count multiple of 4): a vectorised
-        // newline count, then a short walk back over the unfinished last record; the records themselves
-        // are parsed and counted on the device
-        size_t cut = 0;
-        uint64_t lines = lines_before + count_newlines(d, n), lines_at_cut = lines_before;
-        {
-            uint64_t back = lines & 3;
-            size_t end = n;
-            const uint8_t *p = (const uint8_t *)memrchr(d, '\n', end);
-            while (p && back) { end = (size_t)(p - d); p = (const uint8_t *)memrchr(d, '\n', end); --back; }
-            if (p) { cut = (size_t)(p - d) + 1; lines_at_cut = lines - (lines & 3); }
-        }
-        if (eof) {
-            // the tail must be whole records; a last record may lack its final newline
-            if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
-            cut = n;
-            lines_at_cut = lines + (n && d[n - 1] != '\n' ? 1 : 0);
-        } else if (cut == 0) {
-            st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
-        }
-        if (st->not_fastq4) { close_all(); q->producer_done(); return; }
-        carry_len = n - cut;
-        if (!eof) {
-            // the next chunk starts with the carry; in front of it goes what is left of the 32 KiB window
-            const size_t want = carry_len >= GzInflater::kWindow ? carry_len : GzInflater::kWindow;
-            const size_t have = (size_t)std::min<uint64_t>(own ? produced : 0, want); // zlib keeps its own window
-            const size_t keep = have > carry_len ? have : carry_len;
-            tail.assign(d + n - keep, d + n);
-        }
-        c.size = cut;
-        st->bytes += cut;
-        st->lines = lines_at_cut;
-        lines_before = lines_at_cut;
-        first = false;
-        t_cut += secs(t0, now());
-        t0 = now();
-        if (cut) q->put(std::move(c));
-        t_put += secs(t0, now());
-        if (eof || q->aborted()) break;
-    }
-    close_all();
-    q->producer_done();
-}
-
-uint64_t guess_inflated_bytes(const char *path)
-{
-    struct stat sb;
-    if (stat(path, &sb) != 0) return 0;
-    return (uint64_t)sb.st_size * (is_gzip_file(path) ? 8 : 1);
-}
-} // namespace
-
-// ---- bulk ingest of an uncompressed FASTQ file -------------------------------------------
-// The whole file goes into ONE device buffer and ONE push: reader threads pread() disjoint
-// ranges of a 64 MiB block into a pinned staging slot, the block is copied to its place in the
-// device buffer on a copy stream while the next block is being read, and the device parser
-// finds the records itself (line phase by look-back), so the host never scans the bytes.
-namespace {
-constexpr size_t kBulkBlock = 64u << 20;
-
-struct BulkFile {
-    uint8_t *d_buf = nullptr;
-    uint64_t size = 0;
-    std::vector<uint8_t> head; // first bytes of the file (record name / comment)
-};
-
-static int ensure_pinned_ring()
-{
-    if (!g.copy_stream) HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < Engine::kPinnedSlots; ++i) {
-        if (!g.pinned[i]) HIPCHK(hipHostMalloc((void **)&g.pinned[i], kBulkBlock, hipHostMallocDefault));
-        if (!g.pinned_free[i]) HIPCHK(hipEventCreateWithFlags(&g.pinned_free[i], hipEventDisableTiming));
-    }
-    return MHX_OK;
-}
-
-// reads [off, off + len) of fd into dst with `nthreads` parallel preads; false on a short read
-static bool parallel_pread(int fd, uint8_t *dst, uint64_t off, size_t len, int nthreads)
-{
-    std::vector<std::thread> th;
-    std::vector<int> ok((size_t)nthreads, 1);
-    const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
-    for (int t = 0; t < nthreads; ++t) {
-        const size_t b = (size_t)t * per;
-        if (b >= len) break;
-        const size_t e = std::min(len, b + per);
-        th.emplace_back([=, &ok]() {
-            size_t done = b;
-            while (done < e) {
-                const ssize_t got = pread(fd, dst + done, e - done, (off_t)(off + done));
-                if (got <= 0) { ok[(size_t)t] = 0; return; }
-                done += (size_t)got;
-            }
-        });
-    }
-    for (auto &t : th) t.join();
-    for (int v : ok) if (!v) return false;
-    return true;
-}
-
-// MHX_OK and f->d_buf set, or MHX_OK with d_buf == nullptr when the file should take another path
-static int bulk_load_plain(const char *path, BulkFile *f)
-{
-    struct stat sb;
-    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) return MHX_OK;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MHX_OK;
-    if ((uint64_t)sb.st_size + (4ull << 30) > free_b / 2) return MHX_OK; // leave room for tables and other files
-    int rc = ensure_pinned_ring();
-    if (rc) return rc;
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
-    f->size = (uint64_t)sb.st_size;
-    if (hipMalloc((void **)&f->d_buf, f->size + 64) != hipSuccess) { close(fd); f->d_buf = nullptr; return MHX_OK; }
-    int nthreads = (int)std::thread::hardware_concurrency();
-    if (nthreads > 16) nthreads = 16;
-    if (nthreads < 1) nthreads = 1;
-    uint64_t off = 0;
-    int slot = 0;
-    rc = MHX_OK;
-    while (off < f->size && !rc) {
-        const size_t len = (size_t)std::min<uint64_t>(kBulkBlock, f->size - off);
-        if (hipEventSynchronize(g.pinned_free[slot]) != hipSuccess) { rc = fail(MHX_E_HIP, "pinned slot wait failed"); break; }
-        if (!parallel_pread(fd, g.pinned[slot], off, len, len >= (8u << 20) ? nthreads : 1)) { rc = fail(MHX_E_IO, "ERROR: reading %s failed", path); break; }
-        if (off == 0) f->head.assign(g.pinned[slot], g.pinned[slot] + std::min<size_t>(len, 1u << 20));
-        if (hipMemcpyAsync(f->d_buf + off, g.pinned[slot], len, hipMemcpyHostToDevice, g.copy_stream) != hipSuccess ||
-            hipEventRecord(g.pinned_free[slot], g.copy_stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); break; }
-        off += len;
-        slot = (slot + 1) % Engine::kPinnedSlots;
-    }
-    close(fd);
-    if (!rc && hipMemsetAsync(f->d_buf + f->size, 0, 64, g.copy_stream) != hipSuccess) rc = fail(MHX_E_HIP, "memset failed");
-    if (!rc && hipStreamSynchronize(g.copy_stream) != hipSuccess) rc = fail(MHX_E_HIP, "copy stream sync failed");
-    if (rc) { hipStreamSynchronize(g.copy_stream); hipFree(f->d_buf); f->d_buf = nullptr; }
-    return rc;
-}
-
-// name / comment of the first record mash would count (sequence of at least k bytes) in `buf`; false
-// when none of the records there is long enough (name / comment then hold the first header as a last resort)
-static bool first_counted_header(const uint8_t *buf, size_t n, int k, std::string &name, std::string &comment)
-{
-    size_t p = 0;
-    while (p < n) {
-        const uint8_t *h_end = (const uint8_t *)memchr(buf + p, '\n', n - p);
-        if (!h_end) break;
-        const size_t s0 = (size_t)(h_end - buf) + 1;
-        const uint8_t *s_end = s0 < n ? (const uint8_t *)memchr(buf + s0, '\n', n - s0) : nullptr;
-        const size_t s1 = s_end ? (size_t)(s_end - buf) : n;
-        const size_t seq_len = s1 - s0 - ((s1 > s0 && buf[s1 - 1] == '\r') ? 1 : 0); // CRLF files: the CR is not a base
-        if (seq_len >= (size_t)k) { first_header(buf + p, s1 - p, name, comment); return true; }
-        // skip the '+' and quality lines
-        size_t q = s1 + 1;
-        for (int i = 0; i < 2 && q < n; ++i) {
-            const uint8_t *e = (const uint8_t *)memchr(buf + q, '\n', n - q);
-            q = e ? (size_t)(e - buf) + 1 : n;
-        }
-        p = q;
-    }
-    first_header(buf, n, name, comment);
-    return false;
-}
-
-// Which record names the reference: the first counted record of the lowest-numbered file that has one
-// (within its first chunk); the very first header if no file has any.
-struct HeaderPick {
-    int file = -1;        // file that provided a counted record
-    bool fallback = false;
-    std::string name, comment, fb_name, fb_comment;
-    void offer(int f, const uint8_t *buf, size_t n, int k)
-    {
-        if (file >= 0 && f > file) return;
-        std::string nm, cm;
-        if (first_counted_header(buf, n, k, nm, cm)) { file = f; name = nm; comment = cm; }
-        else if (!fallback || f == 0) { fallback = true; fb_name = nm; fb_comment = cm; }
-    }
-    void result(std::string &nm, std::string &cm) const
-    {
-        if (file >= 0) { nm = name; cm = comment; }
-        else { nm = fb_name; cm = fb_comment; }
-    }
-};
-} // namespace
-
-// returns MHX_OK with *handled = true when the streaming path produced the sketch;
-// *handled = false means "not strict FASTQ / could not size": use the whole-file path.
-static int stream_fastq_reference(const char *const *paths, int n_paths, int k, uint32_t s, uint32_t m, std::vector<uint64_t> &hashes,
-                                  std::vector<uint32_t> &counts, uint64_t *kmers, uint64_t *records, std::string *fname,
-                                  std::string *fcomment, bool *handled, bool force_zlib = false)
-{
-    *handled = false;
-    uint64_t expected = 0;
-    for (int i = 0; i < n_paths; ++i) expected += guess_inflated_bytes(paths[i]);
-    mhx_sketcher *sk = nullptr;
-    int rc = mhx_sketcher_create(k, s, m, expected, &sk);
-    if (rc) return rc;
-    bool fallback = false;
-    HeaderPick header;
-    // 1. uncompressed files: whole file -> one device buffer -> one push (see bulk_load_plain).  The buffers
-    // stay on the device until the sketch is final, so that a too-small admission budget can be repaired by
-    // pushing them again into a larger sketcher instead of reading the files a second time.
-    std::vector<int> queued; // files that go through an inflate thread instead
-    std::vector<BulkFile> resident;
-    auto free_resident = [&]() { for (auto &b : resident) hipFree(b.d_buf); resident.clear(); };
-    for (int i = 0; i < n_paths && !rc && !fallback; ++i) {
-        if (is_gzip_file(paths[i]) || getenv("MHX_NO_BULK")) { queued.push_back(i); continue; }
-        BulkFile bf;
-        rc = bulk_load_plain(paths[i], &bf);
-        if (rc) break;
-        if (!bf.d_buf) { queued.push_back(i); continue; }
-        if (bf.head.empty() || bf.head[0] != '@') fallback = true;
-        if (!fallback) header.offer(i, bf.head.data(), bf.head.size(), k);
-        if (!fallback) rc = mhx_sketcher_push_device(sk, bf.d_buf, bf.size, MHX_FMT_FASTQ4);
-        if (hipStreamSynchronize(g.stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "stream sync failed");
-        bf.head.clear();
-        resident.push_back(std::move(bf));
-    }
-    // 2. compressed files: one inflate thread per file, 32 MiB record-aligned chunks
-    uint8_t *d_slot = nullptr;
-    if (!rc && !fallback && !queued.empty() && hipMalloc((void **)&d_slot, kIngestChunk + GzInflater::kOvershoot + 64) != hipSuccess)
-        rc = fail(MHX_E_HIP, "hipMalloc failed for the ingest slot");
-    std::vector<FileIngestState> st(n_paths);
-    if (!rc && !fallback && !queued.empty()) {
-        ChunkQueue q;
-        std::vector<std::thread> threads;
-        for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
-        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, &q, &st[i]);
-        IngestChunk c;
-        while (q.get(c)) {
-            if (rc) continue; // drain
-            if (c.first_of_file) header.offer(c.file, c.data(), std::min<size_t>(c.size, 1u << 20), k);
-            if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
-            rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
-            if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
-            if (rc) q.abort();
-            else q.give_back(std::move(c.buf)); // the copy out of it has completed
-        }
-        for (auto &t : threads) t.join();
-    }
-    bool own_failed = false;
-    for (auto &f : st) own_failed = own_failed || f.own_inflate_failed;
-    if (own_failed && !force_zlib) { // the engine's own decoder refused a stream: let zlib have the last word
-        hipFree(d_slot);
-        free_resident();
-        mhx_sketcher_destroy(sk);
-        clear_error();
-        return stream_fastq_reference(paths, n_paths, k, s, m, hashes, counts, kmers, records, fname, fcomment, handled, true);
-    }
-    for (auto &f : st) {
-        if (!f.error.empty() && !rc) rc = fail(MHX_E_IO, "%s", f.error.c_str());
-        if (f.not_fastq4) fallback = true;
-    }
-    uint32_t n = 0;
-    if (!rc && !fallback) {
-        hashes.resize(s);
-        counts.resize(s);
-        rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
-        // admission budget too small (few solid k-mers: the sketch needs hashes the cap rejected): when every
-        // input is still resident on the device, push it again into a sketcher with 16x, 256x ... the budget
-        uint32_t scale = 1;
-        while (rc == MHX_E_CAPACITY && queued.empty() && !resident.empty() && scale < (1u << 20)) {
-            scale *= 16;
-            clear_error();
-            mhx_sketcher_destroy(sk);
-            sk = nullptr;
-            rc = create_sketcher(k, s, m, expected, scale, &sk);
-            for (size_t i = 0; i < resident.size() && !rc; ++i) rc = mhx_sketcher_push_device(sk, resident[i].d_buf, resident[i].size, MHX_FMT_FASTQ4);
-            if (!rc) rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &n);
-        }
-        if (rc == MHX_E_FORMAT || rc == MHX_E_CAPACITY) { fallback = true; rc = MHX_OK; clear_error(); }
-    }
-    if (!rc && !fallback) {
-        uint64_t stt[8];
-        rc = mhx_sketcher_stats(sk, stt);
-        *kmers = stt[0];
-        header.result(*fname, *fcomment);
-        if (!rc) rc = mhx_sketcher_record_count(sk, records); // sequences of >= k bytes, counted by the device parser
-        hashes.resize(n);
-        counts.resize(n);
-        *handled = !rc;
-    }
-    hipFree(d_slot);
-    free_resident();
-    if (sk) mhx_sketcher_destroy(sk);
-    return rc;
-}
-
-static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
-                                const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
-                                double *est_genome_size)
-{
-    clear_error();
-    int rc = require_engine();
-    if (rc) return rc;
-    if (!paths || n_paths <= 0 || !out_msh) return fail(MHX_E_ARG, "sketch: paths and output required");
-    if (!hash_k_supported(k)) return fail(MHX_E_ARG, "k-mer size %d not supported (1..32)", k);
-    SketchSet set;
-    set.kmer_size = (uint32_t)k;
-    set.sketch_size = s;
-    std::string err;
-    std::vector<Loaded> loaded(n_paths);
-    auto no_records = [&](const char *p) {
-        err += std::string("ERROR: Did not find fasta records in \"") + p + "\".\n";
-        put_text(err, stderr_buf, stderr_cap, stderr_need);
-        return fail(MHX_E_NO_RECORDS, "ERROR: Did not find fasta records in \"%s\".", p);
-    };
-    if (reads) {
-        RefSketch ref;
-        uint64_t kmers = 0, count = 0;
-        std::string fname, fcomment;
-        bool streamed = false;
-        if (!getenv("MHX_NO_STREAMING")) {
-            rc = stream_fastq_reference(paths, n_paths, k, s, min_mult ? min_mult : 1, ref.hashes, ref.counts, &kmers, &count, &fname, &fcomment, &streamed);
-            if (rc) return rc;
-        }
-        std::vector<Loaded *> in;
-        if (!streamed) {
-            for (int i = 0; i < n_paths; ++i) {
-                rc = read_all_maybe_gz(paths[i], loaded[i].raw);
-                if (rc) return rc;
-                loaded[i].fastq4 = looks_like_fastq4(loaded[i].raw.data(), loaded[i].raw.size());
-                in.push_back(&loaded[i]);
-            }
-            rc = sketch_reference(in, k, s, min_mult ? min_mult : 1, true, ref.hashes, ref.counts, &kmers);
-            if (rc) return rc;
-        }
-        // name / comment / count: first counted record; count = records seen by the parser,
-        // or lines / 4 when the stream went to the device parser untouched
-        bool any = streamed;
-        for (auto &l : loaded) {
-            if (streamed) break;
-            if (l.rec.records_seen || !l.rec.seq.empty()) {
-                if (!any && l.rec.records) { fname = l.rec.first_name; fcomment = l.rec.first_comment; any = true; }
-                count += l.rec.records;
-            } else if (!l.raw.empty()) {
-                uint64_t lines = 0;
-                for (size_t off = 0; off < l.raw.size();) {
-                    const void *p = memchr(l.raw.data() + off, '\n', l.raw.size() - off);
-                    if (!p) { ++lines; break; }
-                    ++lines;
-                    off = (const uint8_t *)p - l.raw.data() + 1;
-                }
-                if (!any) { first_header(l.raw.data(), l.raw.size(), fname, fcomment); any = true; }
-                count += lines / 4;
-            }
-        }
-        if (kmers == 0 && count == 0) return no_records(paths[0]);
-        double set_size = 0.0, mult = 0.0;
-        if (!ref.hashes.empty()) {
-            set_size = pow(2.0, k > 16 ? 64.0 : 32.0) * (double)ref.hashes.size() / (double)ref.hashes.back();
-            uint64_t sum = 0;
-            for (uint32_t c : ref.counts) sum += c;
-            mult = (double)sum / (double)ref.hashes.size();
-        }
-        ref.name = paths[0];
-        ref.comment = make_comment(fname, fcomment, count);
-        ref.length = (uint64_t)set_size;
-        ref.counts.clear(); // mash stores counts only with -M
-        set.refs.push_back(std::move(ref));
-        err += "Estimated genome size: " + fmt_g(set_size) + "\n";
-        err += "Estimated coverage:    " + fmt_g(mult) + "\n";
-        if (est_genome_size) *est_genome_size = set_size;
-    } else {
-        for (int i = 0; i < n_paths; ++i) {
-            err += std::string("Sketching ") + paths[i] + "...\n";
-            rc = read_all_maybe_gz(paths[i], loaded[i].raw);
-            if (rc) return rc;
-            rc = parse_fastx(loaded[i].raw.data(), loaded[i].raw.size(), k, loaded[i].rec);
-            if (rc) return rc;
-            if (loaded[i].rec.records == 0) return no_records(paths[i]);
-            RefSketch ref;
-            std::vector<Loaded *> in{&loaded[i]};
-            rc = sketch_reference(in, k, s, 1, false, ref.hashes, ref.counts, nullptr);
-            if (rc) return rc;
-            ref.counts.clear();
-            ref.name = paths[i];
-            ref.comment = make_comment(loaded[i].rec.first_name, loaded[i].rec.first_comment, loaded[i].rec.records);
-            ref.length = loaded[i].rec.total_length;
-            set.refs.push_back(std::move(ref));
-            loaded[i] = Loaded();
-        }
-        if (est_genome_size) *est_genome_size = 0.0;
-    }
-    err += std::string("Writing to ") + out_msh + "...\n";
-    rc = msh_write_file(out_msh, set);
-    if (rc) return rc;
-    return put_text(err, stderr_buf, stderr_cap, stderr_need);
-}
-
-static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
-{
-    clear_error();
-    int rc = require_engine();
-    if (rc) return rc;
-    if (!ref_msh || !qry_msh) return fail(MHX_E_ARG, "dist: two sketch paths required");
-    SketchSet R, Q;
-    rc = msh_read_file(ref_msh, R);
-    if (rc) return rc;
-    rc = msh_read_file(qry_msh, Q);
-    if (rc) return rc;
-    if (R.kmer_size != Q.kmer_size)
-        return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different k-mer sizes (%u and %u)", Q.kmer_size, R.kmer_size);
-    if (R.hash_seed != Q.hash_seed) return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different hash seeds");
-    const int k = (int)R.kmer_size;
-    const uint32_t s = R.sketch_size < Q.sketch_size ? R.sketch_size : Q.sketch_size;
-    const uint32_t nr = (uint32_t)R.refs.size(), nq = (uint32_t)Q.refs.size();
-    std::string text;
-    if (nr && nq) {
-        uint32_t stride = 1;
-        for (auto &r : R.refs) stride = std::max<uint32_t>(stride, (uint32_t)r.hashes.size());
-        for (auto &q : Q.refs) stride = std::max<uint32_t>(stride, (uint32_t)q.hashes.size());
-        std::vector<uint64_t> rq((size_t)nr * stride, 0), qq((size_t)nq * stride, 0);
-        std::vector<uint32_t> rl(nr), ql(nq);
-        for (uint32_t i = 0; i < nr; ++i) { rl[i] = (uint32_t)R.refs[i].hashes.size(); if (rl[i]) memcpy(&rq[(size_t)i * stride], R.refs[i].hashes.data(), (size_t)rl[i] * 8); }
-        for (uint32_t i = 0; i < nq; ++i) { ql[i] = (uint32_t)Q.refs[i].hashes.size(); if (ql[i]) memcpy(&qq[(size_t)i * stride], Q.refs[i].hashes.data(), (size_t)ql[i] * 8); }
-        std::vector<uint32_t> common((size_t)nq * nr), denom((size_t)nq * nr);
-        std::vector<double> dist((size_t)nq * nr);
-        rc = mhx_dist_batch(qq.data(), ql.data(), nq, rq.data(), rl.data(), nr, stride, k, s, common.data(), denom.data(), dist.data(), 0);
-        if (rc) return rc;
-        for (uint32_t qi = 0; qi < nq; ++qi)
-            for (uint32_t ri = 0; ri < nr; ++ri) {
-                const size_t p = (size_t)qi * nr + ri;
-                const double pv = mhx_p_value(common[p], R.refs[ri].length, Q.refs[qi].length, k, denom[p]);
-                text += R.refs[ri].name + "\t" + Q.refs[qi].name + "\t" + fmt_g(dist[p]) + "\t" + fmt_g(pv) + "\t" +
-                        std::to_string(common[p]) + "/" + std::to_string(denom[p]) + "\n";
-            }
-    }
-    return put_text(text, stdout_buf, cap, need);
-}
-
-extern "C" int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_refs, const char *const *names,
-                             const char *const *comments, const uint64_t *lengths, const uint64_t *const *hashes,
-                             const uint32_t *n_hashes)
-{
-    clear_error();
-    if (!path || (n_refs && (!names || !comments || !lengths || !hashes || !n_hashes))) return fail(MHX_E_ARG, "null argument");
-    SketchSet set;
-    set.kmer_size = (uint32_t)k;
-    set.sketch_size = s;
-    set.refs.resize(n_refs);
-    for (uint32_t i = 0; i < n_refs; ++i) {
-        set.refs[i].name = names[i] ? names[i] : "";
-        set.refs[i].comment = comments[i] ? comments[i] : "";
-        set.refs[i].length = lengths[i];
-        if (n_hashes[i]) set.refs[i].hashes.assign(hashes[i], hashes[i] + n_hashes[i]);
-    }
-    return msh_write_file(path, set);
-}
-
-extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
-                                const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
-                                double *est_genome_size)
-{
-    try {
-        return mhx_sketch_files_impl(paths, n_paths, k, s, reads, min_mult, out_msh, stderr_buf, stderr_cap, stderr_need, est_genome_size);
-    } catch (const std::bad_alloc &) {
-        return fail(MHX_E_INTERNAL, "mhx_sketch_files: out of host memory");
-    } catch (const std::exception &e) {
-        return fail(MHX_E_INTERNAL, "mhx_sketch_files: %s", e.what());
-    }
-}
-
-extern "C" int mhx_dist_files(const char *ref_msh, const char *qry_msh, char *stdout_buf, size_t cap, size_t *need)
-{
-    try {
-        return mhx_dist_files_impl(ref_msh, qry_msh, stdout_buf, cap, need);
-    } catch (const std::bad_alloc &) {
-        return fail(MHX_E_INTERNAL, "mhx_dist_files: out of host memory");
-    } catch (const std::exception &e) {
-        return fail(MHX_E_INTERNAL, "mhx_dist_files: %s", e.what());
-    }
 }
 
 extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
