@@ -87,6 +87,14 @@ def test_compute_calls_fail_loudly_without_gpu(lib, tmp_path):
         engine.dist_files(REFDATA / "ref_sketch.msh", REFDATA / "ref_sketch.msh")
     with pytest.raises(engine.EngineError):
         engine.Sketcher(21, 1000)
+    with pytest.raises(engine.EngineError):
+        engine.Sketcher(21, 1000, 3, budget_scale=16)
+    q = np.arange(1, 101, dtype=np.uint64).reshape(1, 100)
+    with pytest.raises(engine.EngineError) as e:
+        engine.dist_batch(q, [100], q, [100], 21, 100)
+    assert e.value.code == engine.MHX_E_NO_DEVICE
+    # the host-only entry points keep working: bounds text, container writer, gunzip
+    assert "Parameters (run with -h for details)" in engine.bounds(27, 0.99)
 
 
 # ---- the ingest's own gzip/DEFLATE decoder against zlib ------------------------------------------
