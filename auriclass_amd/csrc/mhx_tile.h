@@ -145,7 +145,7 @@ struct LineLenCheck {
 MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_bytes, uint32_t word_off,
                              uint32_t check_limit, bool &bad_format, LineLenCheck *lc = nullptr)
 {
-    uint32_t m = 0, cur = 0xFFFFFFFFu;
+    uint32_t m = 0, cur = 0xFFFFFFFFu, pend = 0;
     while (nl) {
         const uint32_t b = nl & (0u - nl);
         const uint32_t below = b - 1u;
@@ -158,20 +158,25 @@ MHX_HD uint32_t seqline_mask(uint32_t nl, uint32_t line, const uint8_t *tile_byt
                 const uint8_t c = tile_bytes[pos];
                 if (((line & 3u) == 0u && c != '@') || ((line & 3u) == 2u && c != '+')) bad_format = true;
             }
-            if (lc && (line & 3u) == 1u) { // a sequence line starts at tile byte `pos`
-                const uint32_t wq = pos >> 5, sh = pos & 31u;
-                const uint32_t window = funnel_bits(lc->nlmap[wq + 1], lc->nlmap[wq], sh); // newline bits of bytes pos..pos+31
-                const uint32_t first_k = lc->k >= 32 ? 0xFFFFFFFFu : ((1u << lc->k) - 1u);
-                if ((window & first_k) == 0 && lc->tile_off + pos + lc->k <= lc->end) {
-                    // a '\r' that ends the line is not part of the sequence (kseq drops it): if the k-th byte
-                    // is a CR followed by the newline (or by the end of the stream) the line has k-1 bases
-                    const uint32_t after = pos + lc->k;
-                    const bool ends_here = lc->tile_off + after >= lc->end || ((lc->nlmap[after >> 5] >> (after & 31u)) & 1u);
-                    if (!(tile_bytes[after - 1u] == '\r' && ends_here)) ++lc->count;
-                }
-            }
+            if (lc && (line & 3u) == 1u) pend |= b; // a sequence line starts behind this newline: measured below
         }
         nl &= nl - 1u;
+    }
+    // the length test of the sequence lines that start in this word, outside the per-newline loop (which
+    // every lane of the wave sits through once per newline of the busiest lane)
+    while (pend) {
+        const uint32_t pos = word_off + (uint32_t)__builtin_ctz(pend) + 1u;
+        const uint32_t wq = pos >> 5, sh = pos & 31u;
+        const uint32_t window = funnel_bits(lc->nlmap[wq + 1], lc->nlmap[wq], sh); // newline bits of bytes pos..pos+31
+        const uint32_t first_k = lc->k >= 32 ? 0xFFFFFFFFu : ((1u << lc->k) - 1u);
+        if ((window & first_k) == 0 && lc->tile_off + pos + lc->k <= lc->end) {
+            // a '\r' that ends the line is not part of the sequence (kseq drops it): if the k-th byte
+            // is a CR followed by the newline (or by the end of the stream) the line has k-1 bases
+            const uint32_t after = pos + lc->k;
+            const bool ends_here = lc->tile_off + after >= lc->end || ((lc->nlmap[after >> 5] >> (after & 31u)) & 1u);
+            if (!(tile_bytes[after - 1u] == '\r' && ends_here)) ++lc->count;
+        }
+        pend &= pend - 1u;
     }
     if ((line & 3u) == 1u) m |= cur;
     return m;
