@@ -113,7 +113,6 @@ struct mhx_sketcher {
     uint64_t nslots = 0;
     uint64_t hash_max = 0;   // largest representable hash (2^64-1 or 2^32-1)
     uint64_t t_init = 0;     // initial admission threshold (everything admitted)
-    uint64_t t_write = 0;    // staging word for thresholds the host imposes
     // device
     uint64_t *d_keys = nullptr;
     uint32_t *d_cnts = nullptr;
@@ -364,10 +363,9 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
                 const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
                 const long double cap_frac = 48.0L * s_eff * (long double)sk->admit_scale / (long double)after;
                 if (cap_frac < t_frac) {
-                    sk->t_write = (uint64_t)(cap_frac * (long double)sk->hash_max);
-                    HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_write, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-                    HIPCHK(hipStreamSynchronize(g.stream)); // t_write is reused by the next launch
-                    sk->last_T = sk->t_write;
+                    const uint64_t cap = (uint64_t)(cap_frac * (long double)sk->hash_max);
+                    HIPCHK(launch_cap_threshold(sk->d_thresh, cap, g.stream)); // on the stream, in front of the tile launch
+                    sk->last_T = cap;
                     sk->bounded = true;
                 }
             }

@@ -362,6 +362,18 @@ __global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
     }
 }
 
+// host-imposed cap of the admission threshold (multiplicity filter, before s solid hashes exist): T = min(T, cap)
+__global__ void cap_threshold_kernel(uint64_t *thresh, uint64_t cap)
+{
+    if (*thresh > cap) *thresh = cap;
+}
+
+hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(cap_threshold_kernel, dim3(1), dim3(1), 0, st, thresh, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st)
 {
     // few, long-running workgroups: each one flushes its 2048-bin LDS histogram with global atomics
