@@ -215,6 +215,7 @@ def main() -> None:
             sample = fq[: n_s * rb].cpu().numpy()
             want, cpu_s, cores = cpu_baseline_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
             cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": cores,
+                            "per_core": round(n_s * args.read_len / cpu_s / 1e9 / max(1, cores), 5),
                             "kind": "port",
                             "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input in {cores} record "
                                       f"shards, one process each: parse + sketch by the C oracle (oracle/mashcore.c), partial "
