@@ -113,3 +113,36 @@ def shard_bounds(n_records: int, world: int, rank: int) -> Tuple[int, int]:
     base, extra = divmod(n_records, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def fastq_record_cuts(data, world: int) -> List[int]:
+    """Byte offsets [c_0 = 0, c_1, ..., c_world = len] that cut a 4-line FASTQ held in `data` (bytes, memoryview
+    or a uint8 numpy array) into `world` record-aligned shards of roughly equal size: cut r is the first record
+    start at or after r * len / world.  A record start is a line that begins with '@', whose
+    successor line does not begin with '@' or '+' ... and whose line after that begins with '+' -- the shape no
+    quality line can imitate over two lines (a quality line may begin with '@', but then the line after it is a
+    header, which begins with '@' as well, not '+')."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    n = len(buf)
+    cuts = [0]
+    for r in range(1, world):
+        pos = r * n // world
+        cut = n
+        # scan line starts from pos on; a handful of lines suffices
+        i = pos
+        if i > 0:
+            nl = np.flatnonzero(buf[i - 1:min(n, i + (1 << 20))] == 10)
+            i = n if len(nl) == 0 else i - 1 + int(nl[0]) + 1
+        while i < n:
+            window = buf[i:min(n, i + (1 << 20))]
+            nls = np.flatnonzero(window == 10)
+            if len(nls) < 2:
+                break
+            l1, l2 = i + int(nls[0]) + 1, i + int(nls[1]) + 1       # starts of the next two lines
+            if buf[i] == 64 and l2 < n and buf[l2] == 43 and (l1 >= n or buf[l1] != 64):
+                cut = i
+                break
+            i = l1
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(n)
+    return cuts

@@ -114,3 +114,49 @@ def test_device_slab_exchange_over_rccl_equals_finish(tmp_path, k, s, m):
     assert np.array_equal(np.load(tmp_path / "slab_h.npy"), want)
     assert np.array_equal(np.load(tmp_path / "fin_h.npy"), want)
     assert np.array_equal(np.load(tmp_path / "slab_c.npy"), np.load(tmp_path / "fin_c.npy"))
+
+
+def _ragged_input():
+    rng = np.random.default_rng(33)
+    genome = synth.make_genome(150_000, seed=34)
+    quals = np.frombuffer(b"@+!#IJ5<?ACGT", np.uint8)
+    recs = []
+    for i in range(40_000):
+        L = int(rng.integers(20, 251))
+        p0 = int(rng.integers(0, len(genome) - L))
+        recs.append(b"@r%d" % i + b"\n" + genome[p0:p0 + L].tobytes() + b"\n+\n" + bytes(rng.choice(quals, size=L)) + b"\n")
+    return b"".join(recs)
+
+
+def _byte_range_worker(rank, world, port, k, s, m, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auriclass_amd import engine
+
+    engine.init(0)
+    data = np.frombuffer(_ragged_input(), dtype=np.uint8)
+    cuts = multigpu.fastq_record_cuts(data, world)
+    shard = torch.from_numpy(data[cuts[rank]:cuts[rank + 1]].copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    sk = engine.Sketcher(k, s, m, expected_bytes=shard.numel())
+    sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+    got_h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, s, m, engine.merge_partials, torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"b{rank}.npy"), got_h)
+    sk.close()
+    dist.destroy_process_group()
+
+
+def test_byte_range_shards_of_a_ragged_fastq(tmp_path):
+    """SURVEY.md 8(e) partitioning: every rank takes the byte range [r*B/R, (r+1)*B/R) of ONE ragged FASTQ,
+    snapped to record starts (multigpu.fastq_record_cuts), sketches it on the GPU and joins the exchange."""
+    from oracle import mash_oracle as mo
+
+    k, s, m, world = 21, 2000, 2, 3
+    mp.spawn(_byte_range_worker, args=(world, _free_port(), k, s, m, str(tmp_path)), nprocs=world, join=True)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(_ragged_input())
+    want, _ = ref.finish()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"b{r}.npy"), want), f"rank {r}"

@@ -88,3 +88,32 @@ def test_shard_bounds_cover_everything_once():
             spans = [multigpu.shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_fastq_record_cuts_land_on_record_starts():
+    """Byte-range sharding of a real-looking FASTQ: ragged reads, quality lines that begin with '@' or '+',
+    CRLF; every cut must be the start of a record and the shards must tile the file."""
+    rng = np.random.default_rng(5)
+    quals = np.frombuffer(b"@+!#IJ5<?ACGT", np.uint8)
+    for nl in (b"\n", b"\r\n"):
+        recs, starts, off = [], set(), 0
+        for i in range(3000):
+            L = int(rng.integers(1, 300))
+            seq = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L))
+            q = bytes(rng.choice(quals, size=L))
+            if i % 7 == 0:
+                q = b"@" + q[1:]
+            if i % 11 == 0:
+                q = b"+" + q[1:]
+            rec = b"@read%d some text" % i + nl + seq + nl + b"+" + nl + q + nl
+            starts.add(off)
+            off += len(rec)
+            recs.append(rec)
+        data = b"".join(recs)
+        for world in (1, 2, 3, 8, 64):
+            cuts = multigpu.fastq_record_cuts(data, world)
+            assert cuts[0] == 0 and cuts[-1] == len(data) and len(cuts) == world + 1
+            assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+            assert all(c in starts or c == len(data) for c in cuts)
+            sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+            assert max(sizes) <= len(data) // world + 2000
