@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 import os
 
 FUZZ = int(os.environ.get("MHX_FUZZ_SCALE", "1"))   # MHX_FUZZ_SCALE=10: ten times the randomised cases
+FUZZ0 = int(os.environ.get("MHX_FUZZ_OFFSET", "0"))  # first seed index: other values explore other cases
+
+
+def _seeds(n):
+    return range(FUZZ0, FUZZ0 + n * FUZZ)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -519,7 +524,7 @@ def test_corrupt_gz_is_reported_after_zlib_had_the_last_word(tmp_path):
         engine.sketch_files([p], 21, 1000, tmp_path / "x.msh", reads=True, min_mult=1)
 
 
-@pytest.mark.parametrize("seed", range(12 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
     """Random k (1..32), sketch size, multiplicity, read-length distribution, N / lower-case content,
     CRLF or LF, number of pushes and device-pointer alignment; every case against the oracle, counts
@@ -584,7 +589,7 @@ def test_randomised_sweep_of_parameters_formats_and_push_patterns(seed):
         assert np.array_equal(got_c, brute_c)
 
 
-@pytest.mark.parametrize("seed", range(8 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_randomised_file_level_reads_mode(tmp_path, seed):
     """Random mixes of plain and gzipped FASTQ files (1..3 files, some empty of long reads, some with
     CRLF, some without a final newline) through mhx_sketch_files in reads mode: .msh bytes and the
@@ -628,7 +633,7 @@ def test_randomised_file_level_reads_mode(tmp_path, seed):
     assert "Estimated genome size: %g\n" % ref.set_size in stderr
 
 
-@pytest.mark.parametrize("seed", range(6 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_randomised_dist_batches(seed):
     """Random batch shapes for mash's compareSketches on the device: 1..40 references (both sides of the
     32-reference fast path), ragged list lengths, shared fractions from 0 to 1, tiny and full sketches."""
@@ -651,7 +656,7 @@ def test_randomised_dist_batches(seed):
     _check_all_pairs(qrys, refs, k, s)
 
 
-@pytest.mark.parametrize("seed", range(5 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(5))
 def test_randomised_medium_inputs_with_multiplicity_filter(seed):
     """3-60 MB inputs (hundreds to thousands of tiles, several tighten stages) over random genome sizes
     and coverages from well below 1x to a few hundred x, m in 1..5, s from 100 to 50000, one to three
@@ -721,7 +726,7 @@ def test_shallow_sample_with_multiplicity_filter_needs_every_solid_kmer(tmp_path
     assert got.comment == ref.comment()
 
 
-@pytest.mark.parametrize("seed", range(6 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_randomised_sequence_streams_with_arbitrary_bytes(seed):
     """MHX_FMT_SEQ: any byte that is not A/C/G/T (either case) ends a k-mer run -- newlines, NUL, 0xFF,
     '>', '@', CR, digits.  Random streams with such bytes sprinkled in, random k / s / m, random split into
@@ -772,7 +777,7 @@ def test_randomised_sequence_streams_with_arbitrary_bytes(seed):
     assert np.array_equal(got_c, want_c)
 
 
-@pytest.mark.parametrize("seed", range(5 * FUZZ))
+@pytest.mark.parametrize("seed", _seeds(5))
 def test_randomised_fasta_files(tmp_path, seed):
     """FASTA mode (one reference per file): random record counts and lengths (some shorter than k), line
     widths, lower case, IUPAC codes, blank lines between records, CRLF, plain or gzip; .msh bytes against
