@@ -618,26 +618,43 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
             rc = sketch_reference(in, k, s, min_mult ? min_mult : 1, true, ref.hashes, ref.counts, &kmers);
             if (rc) return rc;
         }
-        // name / comment / count: first counted record; count = records seen by the parser,
-        // or lines / 4 when the stream went to the device parser untouched
+        // name / comment / count: the first counted record and the number of counted ones (sequence of at least
+        // k bytes) -- from the record parser where it ran, from a 4-line walk over the raw bytes where the stream
+        // went to the device parser untouched
         bool any = streamed;
+        std::string fb_name, fb_comment;
+        bool have_fb = false;
         for (auto &l : loaded) {
             if (streamed) break;
             if (l.rec.records_seen || !l.rec.seq.empty()) {
                 if (!any && l.rec.records) { fname = l.rec.first_name; fcomment = l.rec.first_comment; any = true; }
                 count += l.rec.records;
             } else if (!l.raw.empty()) {
-                uint64_t lines = 0;
-                for (size_t off = 0; off < l.raw.size();) {
-                    const void *p = memchr(l.raw.data() + off, '\n', l.raw.size() - off);
-                    if (!p) { ++lines; break; }
-                    ++lines;
-                    off = (const uint8_t *)p - l.raw.data() + 1;
+                const uint8_t *b = l.raw.data();
+                const size_t n = l.raw.size();
+                if (!have_fb) { first_header(b, n, fb_name, fb_comment); have_fb = true; }
+                size_t p = 0;
+                while (p < n) { // one record: header, sequence, '+', quality
+                    const uint8_t *e0 = (const uint8_t *)memchr(b + p, '\n', n - p);
+                    if (!e0) break;
+                    const size_t s0 = (size_t)(e0 - b) + 1;
+                    const uint8_t *e1 = s0 < n ? (const uint8_t *)memchr(b + s0, '\n', n - s0) : nullptr;
+                    const size_t s1 = e1 ? (size_t)(e1 - b) : n;
+                    const size_t len = s1 - s0 - ((s1 > s0 && b[s1 - 1] == '\r') ? 1 : 0);
+                    if (len >= (size_t)k) {
+                        if (!any) { first_header(b + p, s1 - p, fname, fcomment); any = true; }
+                        ++count;
+                    }
+                    size_t q = s1 + 1;
+                    for (int i = 0; i < 2 && q < n; ++i) {
+                        const uint8_t *e = (const uint8_t *)memchr(b + q, '\n', n - q);
+                        q = e ? (size_t)(e - b) + 1 : n;
+                    }
+                    p = q;
                 }
-                if (!any) { first_header(l.raw.data(), l.raw.size(), fname, fcomment); any = true; }
-                count += lines / 4;
             }
         }
+        if (!any && have_fb) { fname = fb_name; fcomment = fb_comment; }
         if (kmers == 0 && count == 0) return no_records(paths[0]);
         double set_size = 0.0, mult = 0.0;
         if (!ref.hashes.empty()) {
