@@ -865,3 +865,43 @@ def test_thousands_of_tiny_pushes_with_multiplicity_filter():
     ref = mo.Sketcher(21, 2000, 3)
     ref.add_fastx(fq.cpu().numpy().tobytes())
     assert np.array_equal(got, ref.finish()[0])
+
+
+@pytest.mark.parametrize("seed", _seeds(2))
+def test_randomised_ragged_multi_chunk_gz(tmp_path, seed):
+    """A ~70 MB .fq.gz of ragged reads (lengths 1..400, qualities that begin with '@' or '+', N's, some CRLF
+    files): several 32 MiB chunks cut at record boundaries by newline counting, DEFLATE matches reaching
+    back across the chunk borders, against the oracle."""
+    import gzip
+
+    rng = np.random.default_rng(8600 + seed)
+    k = int(rng.choice([16, 21, 31]))
+    s = int(rng.choice([1000, 20000]))
+    m = int(rng.choice([1, 2]))
+    genome = synth.make_genome(int(rng.integers(50_000, 400_000)), seed=400 + seed).tobytes()
+    nl = b"\r\n" if rng.random() < 0.3 else b"\n"
+    quals = np.frombuffer(b"@+!#IJ5<?ACGT", np.uint8)
+    n_reads = 180_000
+    lens = rng.integers(1, 401, n_reads)
+    starts = rng.integers(0, len(genome) - 401, n_reads)
+    qual_pool = bytes(rng.choice(quals, size=4096))
+    parts = []
+    for i in range(n_reads):
+        L = int(lens[i])
+        seq = genome[int(starts[i]):int(starts[i]) + L]
+        if i % 97 == 0 and L > 3:
+            seq = seq[:L // 2] + b"N" + seq[L // 2 + 1:]
+        q0 = int(starts[i]) % (4096 - 401)
+        parts.append(b"@r%d/1" % i + nl + seq + nl + b"+" + nl + qual_pool[q0:q0 + L] + nl)
+    data = b"".join(parts)
+    assert len(data) > (32 << 20) + (32 << 20)
+    p = tmp_path / "ragged.fq.gz"
+    with gzip.open(p, "wb", compresslevel=int(rng.integers(1, 7))) as fh:
+        fh.write(data)
+    engine.sketch_files([p], k, s, tmp_path / "o.msh", reads=True, min_mult=m)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(data)
+    want, _ = ref.finish()
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert np.array_equal(got.hashes, want), (k, s, m)
+    assert got.comment == ref.comment()
