@@ -401,12 +401,17 @@ static int bulk_load_plain(const char *path, BulkFile *f)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MHX_OK;
     if ((uint64_t)sb.st_size + (4ull << 30) > free_b / 2) return MHX_OK; // leave room for tables and other files
-    int rc = ensure_pinned_ring();
-    if (rc) return rc;
+    if (ensure_pinned_ring()) { clear_error(); (void)hipGetLastError(); return MHX_OK; } // no pinned staging: the chunked path will do
+    int rc = MHX_OK;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
     f->size = (uint64_t)sb.st_size;
-    if (hipMalloc((void **)&f->d_buf, f->size + 64) != hipSuccess) { close(fd); f->d_buf = nullptr; return MHX_OK; }
+    if (hipMalloc((void **)&f->d_buf, f->size + 64) != hipSuccess) { // tolerated: forget the sticky error, take the chunked path
+        (void)hipGetLastError();
+        close(fd);
+        f->d_buf = nullptr;
+        return MHX_OK;
+    }
     int nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads > 16) nthreads = 16;
     if (nthreads < 1) nthreads = 1;
