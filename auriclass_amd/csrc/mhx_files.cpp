@@ -223,6 +223,64 @@ static bool read_whole_file(const char *path, std::vector<uint8_t> &out, size_t 
     return got == (size_t)sb.st_size;
 }
 
+// CRC-32 of a gzip member computed BEHIND the decoder: the inflate thread hands over every piece of output as
+// soon as it exists (and the trailer's expectation at a member end); this thread keeps the running CRC.
+class CrcFollower {
+  public:
+    CrcFollower() : th_([this] { run(); }) {}
+    ~CrcFollower()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void piece(const uint8_t *p, size_t n) { push({p, n, 0, false}); }
+    void member_end(uint32_t expected) { push({nullptr, 0, expected, true}); }
+    void drain() // everything handed over so far has been read: its buffers may go elsewhere now
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        idle_.wait(lk, [&] { return q_.empty() && !busy_; });
+    }
+    bool failed() { std::lock_guard<std::mutex> lk(m_); return failed_; }
+
+  private:
+    struct Item { const uint8_t *p; size_t n; uint32_t expected; bool end; };
+    void push(Item it)
+    {
+        { std::lock_guard<std::mutex> lk(m_); q_.push_back(it); }
+        cv_.notify_one();
+    }
+    void run()
+    {
+        uint32_t crc = 0;
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !q_.empty() || stop_; });
+                if (q_.empty()) return;
+                it = q_.front();
+                q_.pop_front();
+                busy_ = true;
+            }
+            bool bad = false;
+            if (it.end) { bad = crc != it.expected; crc = 0; }
+            else crc = crc32_update(crc, it.p, it.n);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                busy_ = false;
+                failed_ = failed_ || bad;
+            }
+            idle_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, idle_;
+    std::deque<Item> q_;
+    bool stop_ = false, busy_ = false, failed_ = false;
+    std::thread th_; // last member: started when the rest is ready
+};
+
 // Producer of one input file: inflates it (own DEFLATE decoder on the whole compressed file in memory;
 // MHX_ZLIB_INFLATE=1 selects zlib's gzread instead; an uncompressed file is simply read) and cuts the
 // stream into record-aligned chunks.
@@ -234,9 +292,11 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
     FILE *plain = nullptr;
     std::vector<uint8_t> zbytes;
     GzInflater inf;
+    std::unique_ptr<CrcFollower> crc_thread; // own decoder only: the CRC pass runs beside the decoding, not after it
     if (own) {
         if (!read_whole_file(path, zbytes, 16)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
         inf.set_input(zbytes.data(), zbytes.size() - 16);
+        if (!getenv("MHX_INLINE_CRC")) { inf.set_deferred_crc(true); crc_thread.reset(new CrcFollower()); }
     } else if (gz) {
         g = gzopen(path, "rb");
         if (g) gzbuffer(g, 1 << 20);
@@ -271,9 +331,21 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
             long got;
             if (own) {
                 const uint64_t hist = produced < GzInflater::kWindow ? produced : GzInflater::kWindow;
-                const size_t r = inf.inflate(d + n, kIngestChunk - n, d + n - hist);
+                // pieces of 1 MiB when the CRC follows on its own thread (it reads them while they are still in cache)
+                const size_t want = crc_thread ? std::min<size_t>(kIngestChunk - n, 1u << 20) : kIngestChunk - n;
+                const size_t r = inf.inflate(d + n, want, d + n - hist);
                 if (r == (size_t)-1) got = -1;
-                else { got = (long)r; produced += r; if (inf.done()) { n += r; eof = true; break; } }
+                else {
+                    got = (long)r;
+                    produced += r;
+                    if (crc_thread) {
+                        uint32_t expected;
+                        if (r) crc_thread->piece(d + n, r);
+                        if (inf.take_member_end(&expected)) crc_thread->member_end(expected);
+                    }
+                    if (inf.done()) { n += r; eof = true; break; }
+                    if (r == 0) continue; // a member ended exactly here: the next call starts the next one
+                }
             } else if (gz) {
                 got = gzread(g, d + n, (unsigned)std::min<size_t>(kIngestChunk - n, 1u << 30));
             } else {
@@ -289,6 +361,16 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
             }
             if (got == 0) { eof = true; break; }
             n += (size_t)got;
+        }
+        if (crc_thread) {
+            crc_thread->drain(); // the follower has read everything of this chunk: it may be cut, queued and recycled
+            if (crc_thread->failed()) {
+                st->error = std::string("ERROR: reading ") + path + " failed";
+                st->own_inflate_failed = true;
+                close_all();
+                q->producer_done();
+                return;
+            }
         }
         t_inflate += secs(t0, now());
         t0 = now();

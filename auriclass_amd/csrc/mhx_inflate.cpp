@@ -109,6 +109,9 @@ struct GzInflater::Impl {
     uint64_t member_out = 0;
     std::string error;
     bool verify_crc = true;
+    // deferred checking: inflate() returns at every member end and reports the trailer's CRC instead of checking it
+    bool defer_crc = false, member_end_pending = false;
+    uint32_t pending_crc = 0;
 
     void refill()
     {
@@ -260,7 +263,8 @@ bool GzInflater::Impl::read_trailer()
     const uint32_t want_len = in[4] | (in[5] << 8) | (in[6] << 16) | ((uint32_t)in[7] << 24);
     in += 8;
     if (want_len != (uint32_t)member_out) return fail("incorrect length check");
-    if (verify_crc && want_crc != crc) return fail("incorrect data check");
+    if (defer_crc) { member_end_pending = true; pending_crc = want_crc; }
+    else if (verify_crc && want_crc != crc) return fail("incorrect data check");
     state = kMemberHeader;
     return true;
 }
@@ -376,6 +380,14 @@ uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
 GzInflater::GzInflater() : impl_(new Impl()) { init_crc(); }
 GzInflater::~GzInflater() { delete impl_; }
 void GzInflater::set_verify_crc(bool on) { impl_->verify_crc = on; }
+void GzInflater::set_deferred_crc(bool on) { impl_->defer_crc = on; }
+bool GzInflater::take_member_end(uint32_t *crc)
+{
+    if (!impl_->member_end_pending) return false;
+    impl_->member_end_pending = false;
+    *crc = impl_->pending_crc;
+    return true;
+}
 const std::string &GzInflater::error() const { return impl_->error; }
 bool GzInflater::done() const { return impl_->state == Impl::kDone; }
 
@@ -403,7 +415,7 @@ size_t GzInflater::inflate(uint8_t *out, size_t limit, const uint8_t *window_sta
     auto account = [&]() {
         const size_t n = (size_t)(o - crc_from);
         if (n) {
-            if (s.verify_crc) s.crc = crc32_update(s.crc, crc_from, n);
+            if (s.verify_crc && !s.defer_crc) s.crc = crc32_update(s.crc, crc_from, n);
             s.member_out += n;
             crc_from = o;
         }
@@ -521,6 +533,7 @@ size_t GzInflater::inflate(uint8_t *out, size_t limit, const uint8_t *window_sta
         case Impl::kTrailer:
             account();
             if (!s.read_trailer()) return (size_t)-1;
+            if (s.member_end_pending) return (size_t)(o - out); // the caller closes the member's CRC here
             break;
         case Impl::kDone:
             account();

@@ -58,6 +58,12 @@ class GzInflater {
     // the compressed file (all members); 16 readable bytes must follow data[n - 1]
     void set_input(const uint8_t *data, size_t n);
     void set_verify_crc(bool on);
+    // Deferred checking: inflate() then returns at every member end (the member's last byte is the last byte it
+    // produced) and take_member_end() hands out the CRC-32 the trailer promises, for a caller that computes the
+    // CRC of the output itself (the ingest does so on a helper thread, behind the decoder).  The length is still
+    // checked here.
+    void set_deferred_crc(bool on);
+    bool take_member_end(uint32_t *crc);
     // Produces output at `out` until `limit` bytes are reached (it may run over by < kOvershoot), the
     // input is exhausted or an error occurs; call again to continue.  [window_start, out) must hold the
     // previous output (up to 32 KiB of it).  Returns the bytes produced or (size_t)-1.

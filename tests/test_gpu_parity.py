@@ -905,3 +905,29 @@ def test_randomised_ragged_multi_chunk_gz(tmp_path, seed):
     got = mo.read_msh(tmp_path / "o.msh").references[0]
     assert np.array_equal(got.hashes, want), (k, s, m)
     assert got.comment == ref.comment()
+
+
+def test_multi_member_gz_and_wrong_crc_through_the_ingest(tmp_path):
+    """The ingest checks every gzip member's CRC-32 on a helper thread that runs behind the decoder: a file of
+    three concatenated members (bgzip style) sketches like their concatenation, and a member with a wrong CRC
+    is refused (after zlib has had the last word)."""
+    import gzip
+
+    genome = synth.make_genome(60_000, seed=81)
+    parts = [synth.make_fastq(genome, n, 120, seed=82 + i, device="cpu", first_index=i * 100_000).numpy().tobytes()
+             for i, n in enumerate((30_000, 1, 45_000))]
+    p = tmp_path / "members.fq.gz"
+    p.write_bytes(b"".join(gzip.compress(x, compresslevel=5) for x in parts))
+    engine.sketch_files([p], 21, 2000, tmp_path / "o.msh", reads=True, min_mult=2)
+    ref = mo.Sketcher(21, 2000, 2)
+    ref.add_fastx(b"".join(parts))
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert np.array_equal(got.hashes, ref.finish()[0])
+    assert got.comment == ref.comment()
+    bad = bytearray(b"".join(gzip.compress(x, compresslevel=5) for x in parts))
+    first_len = len(gzip.compress(parts[0], compresslevel=5))
+    bad[first_len - 8] ^= 0xFF                      # CRC field of the first member
+    q = tmp_path / "badcrc.fq.gz"
+    q.write_bytes(bytes(bad))
+    with pytest.raises(engine.EngineError):
+        engine.sketch_files([q], 21, 2000, tmp_path / "x.msh", reads=True, min_mult=2)
