@@ -145,6 +145,7 @@ struct mhx_sketcher {
     bool established = false;  // the tighten pass has lowered T from solid (count >= m) entries
     uint64_t occupied = 0;     // table occupancy reported by the last tighten pass
     uint64_t solid = 0;        // entries <= T with count >= m reported by the last tighten pass
+    uint64_t slab_state = 0;   // staging word of export_slab (MHX_SLAB_* bits)
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
@@ -623,10 +624,12 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
         keys.push_back(~0ull);
         cnts.push_back((uint32_t)maxkey);
     }
-    // exactness: either nothing was ever rejected, or at least s qualifying hashes lie below T
-    if (keys.size() < sk->s && sk->bounded)
-        return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries); recreate the sketcher with a larger table",
-                    keys.size(), sk->s);
+    // exactness: either nothing was ever rejected (T still at its initial value), or at least s qualifying
+    // hashes lie below T.  Fewer than s below a lowered T means the bound was too tight: a host-imposed cap
+    // of the m > 1 phase (sk->bounded), or -- never seen, ~1e-9 per pass -- a sampled tighten pass that overshot.
+    if (keys.size() < sk->s && T < sk->hash_max)
+        return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries%s); recreate the sketcher with a larger table",
+                    keys.size(), sk->s, sk->bounded ? ", capped threshold" : "");
     sort_pairs(keys, cnts);
     const uint32_t nn = keys.size() < sk->s ? (uint32_t)keys.size() : sk->s;
     memcpy(hashes, keys.data(), (size_t)nn * sizeof(uint64_t));
@@ -677,6 +680,9 @@ extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t
     uint64_t *w = (uint64_t *)d_slab;
     HIPCHK(hipMemsetAsync(w, 0, 3 * sizeof(uint64_t), g.stream));
     HIPCHK(hipMemcpyAsync(w + 1, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+    // host-side state of the m > 1 phase rides in the flags word (the device flags are OR-ed in by the kernel)
+    sk->slab_state = (sk->bounded ? (uint64_t)MHX_SLAB_BOUNDED : 0) | (sk->established ? (uint64_t)MHX_SLAB_ESTABLISHED : 0);
+    if (sk->slab_state) HIPCHK(hipMemcpyAsync(w + 2, &sk->slab_state, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
     HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
@@ -705,6 +711,46 @@ extern "C" int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts
         i = j;
     }
     *n_out = w;
+    return MHX_OK;
+}
+
+// The merge step of the sharded path WITH its exactness rule (what finish() checks on one GPU, applied to
+// the union).  Below T_min = min_r T_r every shard's list is complete and its counts exact (a shard's
+// threshold only ever falls, so a hash <= its final T_r was admitted on every occurrence).  Hence:
+//   >= s merged entries with summed count >= m lie <= T_min  -> the first s are the sketch of the union;
+//   T_min == hash_max (no shard ever rejected anything)      -> whatever qualifies is the (short) sketch;
+//   otherwise the bound was too tight for this input         -> MHX_E_CAPACITY, never a short sketch.
+// The decision uses gathered data only, so every rank reaches the same verdict.
+extern "C" int mhx_merge_shard_partials(const uint64_t *hashes, const uint32_t *counts, const uint64_t *shard_n,
+                                        const uint64_t *shard_threshold, uint32_t n_shards, int k, uint32_t s, uint32_t min_mult,
+                                        uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out)
+{
+    clear_error();
+    if (!shard_n || !shard_threshold || n_shards == 0) return fail(MHX_E_ARG, "null shard description");
+    if (!out_hashes || !n_out || s == 0) return fail(MHX_E_ARG, "null output");
+    if (k < 1 || k > 32) return fail(MHX_E_ARG, "k-mer size %d not supported (1..32)", k);
+    const uint64_t hash_max = k <= 16 ? 0xFFFFFFFFull : ~0ull;
+    uint64_t t_min = ~0ull, total = 0;
+    for (uint32_t r = 0; r < n_shards; ++r) {
+        t_min = shard_threshold[r] < t_min ? shard_threshold[r] : t_min;
+        total += shard_n[r];
+    }
+    if ((!hashes || !counts) && total) return fail(MHX_E_ARG, "null input");
+    try {
+        std::vector<uint64_t> h;
+        std::vector<uint32_t> c;
+        h.reserve(total);
+        c.reserve(total);
+        for (uint64_t i = 0; i < total; ++i)
+            if (hashes[i] <= t_min) { h.push_back(hashes[i]); c.push_back(counts[i]); }
+        int rc = mhx_merge_partials(h.data(), c.data(), h.size(), s, min_mult, out_hashes, out_counts, n_out);
+        if (rc) return rc;
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_merge_shard_partials: out of host memory");
+    }
+    if (*n_out < s && t_min < hash_max)
+        return fail(MHX_E_CAPACITY, "sharded sketch not exact: %u of %u entries with multiplicity >= %u below the smallest shard threshold; "
+                    "every rank must sketch its shard again with a larger budget_scale", *n_out, s, min_mult ? min_mult : 1);
     return MHX_OK;
 }
 

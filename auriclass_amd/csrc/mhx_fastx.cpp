@@ -11,6 +11,9 @@
 
 #include <algorithm>
 
+#include <exception>
+#include <new>
+
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -45,7 +48,7 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     if (getenv("MHX_ZLIB_INFLATE") || stat(path, &sb) != 0 || !S_ISREG(sb.st_mode)) return read_all_zlib(path, out);
     FILE *f = fopen(path, "rb");
     if (!f) return fail(MHX_E_IO, "ERROR: could not open %s for reading", path);
-    std::vector<uint8_t> raw((size_t)sb.st_size + 16, 0);
+    std::vector<uint8_t> raw((size_t)sb.st_size + GzInflater::kInputPad, 0);
     const size_t got = fread(raw.data(), 1, (size_t)sb.st_size, f);
     fclose(f);
     if (got != (size_t)sb.st_size) return fail(MHX_E_IO, "ERROR: reading %s failed", path);
@@ -56,8 +59,10 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     }
     GzInflater inf;
     inf.set_input(raw.data(), got);
-    // size hint: ISIZE of the last member
-    const size_t hint = (size_t)raw[got - 4] | ((size_t)raw[got - 3] << 8) | ((size_t)raw[got - 2] << 16) | ((size_t)raw[got - 1] << 24);
+    // size hint: ISIZE of the last member -- untrusted, so never more than 64x the compressed size up front
+    // (DEFLATE text rarely passes 10x; the doubling below covers whatever the hint missed)
+    size_t hint = (size_t)raw[got - 4] | ((size_t)raw[got - 3] << 8) | ((size_t)raw[got - 2] << 16) | ((size_t)raw[got - 1] << 24);
+    hint = std::min<size_t>(hint, got * 64);
     const size_t slack = GzInflater::kOvershoot + 16;
     out.assign(std::max<size_t>(hint, 1u << 16) + slack, 0);
     size_t n = 0;
@@ -207,10 +212,20 @@ static int sniff(const char *path, char lead)
     return 1;
 }
 
-extern "C" int mhx_sniff_fastq(const char *path) { clear_error(); return path ? sniff(path, '@') : fail(MHX_E_ARG, "null path"); }
-extern "C" int mhx_sniff_fasta(const char *path) { clear_error(); return path ? sniff(path, '>') : fail(MHX_E_ARG, "null path"); }
+static int sniff_guarded(const char *path, char lead)
+{
+    clear_error();
+    if (!path) return fail(MHX_E_ARG, "null path");
+    try {
+        return sniff(path, lead);
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "sniff: %s", e.what());
+    }
+}
+extern "C" int mhx_sniff_fastq(const char *path) { return sniff_guarded(path, '@'); }
+extern "C" int mhx_sniff_fasta(const char *path) { return sniff_guarded(path, '>'); }
 
-extern "C" int mhx_fasta_total_bases(const char *path, uint64_t *total)
+static int fasta_total_bases_impl(const char *path, uint64_t *total)
 {
     clear_error();
     if (!path || !total) return fail(MHX_E_ARG, "null argument");
@@ -222,4 +237,16 @@ extern "C" int mhx_fasta_total_bases(const char *path, uint64_t *total)
     if (rc) return rc;
     *total = pr.total_length;
     return MHX_OK;
+}
+
+// no exception may cross the C boundary (ctypes would abort the process): a crafted .gz can ask for gigabytes
+extern "C" int mhx_fasta_total_bases(const char *path, uint64_t *total)
+{
+    try {
+        return fasta_total_bases_impl(path, total);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_fasta_total_bases: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_fasta_total_bases: %s", e.what());
+    }
 }

@@ -294,8 +294,8 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
     GzInflater inf;
     std::unique_ptr<CrcFollower> crc_thread; // own decoder only: the CRC pass runs beside the decoding, not after it
     if (own) {
-        if (!read_whole_file(path, zbytes, 16)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
-        inf.set_input(zbytes.data(), zbytes.size() - 16);
+        if (!read_whole_file(path, zbytes, GzInflater::kInputPad)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
+        inf.set_input(zbytes.data(), zbytes.size() - GzInflater::kInputPad);
         if (!getenv("MHX_INLINE_CRC")) { inf.set_deferred_crc(true); crc_thread.reset(new CrcFollower()); }
     } else if (gz) {
         g = gzopen(path, "rb");
@@ -832,6 +832,7 @@ extern "C" int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_ref
 {
     clear_error();
     if (!path || (n_refs && (!names || !comments || !lengths || !hashes || !n_hashes))) return fail(MHX_E_ARG, "null argument");
+    try {
     SketchSet set;
     set.kmer_size = (uint32_t)k;
     set.sketch_size = s;
@@ -843,6 +844,11 @@ extern "C" int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_ref
         if (n_hashes[i]) set.refs[i].hashes.assign(hashes[i], hashes[i] + n_hashes[i]);
     }
     return msh_write_file(path, set);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_msh_write: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_msh_write: %s", e.what());
+    }
 }
 
 extern "C" int mhx_sketch_files(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,

@@ -11,6 +11,7 @@
 // tests/test_lib_cpu.py.
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -97,7 +98,7 @@ static bool build_table(const uint8_t *lens, int nsym, int first_bits, uint32_t 
 // of extra bits that follow the code; bits 17..31 = the literal, the base length, the base distance or the
 // sub-table offset.
 struct GzInflater::Impl {
-    const uint8_t *in = nullptr, *in_end = nullptr; // in_end excludes the 16 readable pad bytes
+    const uint8_t *in = nullptr, *in_end = nullptr; // in_end excludes the kInputPad readable pad bytes
     uint64_t bitbuf = 0;
     int bitcnt = 0;
     enum State { kMemberHeader, kBlockHeader, kStored, kHuffman, kTrailer, kDone, kError } state = kMemberHeader;
@@ -113,6 +114,10 @@ struct GzInflater::Impl {
     bool defer_crc = false, member_end_pending = false;
     uint32_t pending_crc = 0;
 
+    // Over-read discipline: the true read position is P = in - (bitcnt >> 3); a refill loads 8 bytes at
+    // `in` <= P + 7, i.e. touches bytes up to P + 14.  Every refill below is preceded (at a distance of at
+    // most 2 consumed bytes) by an input_overrun() test that pins P <= in_end, so no load reaches past
+    // in_end + 17 -- inside the kInputPad (64) zero bytes the caller guarantees behind the input.
     void refill()
     {
         // branch-free refill: valid while 8 bytes at `in` are readable (the buffer is padded)
@@ -176,8 +181,11 @@ bool GzInflater::Impl::read_block_header()
     const uint32_t type = take(2);
     if (type == 0) {
         byte_align();
+        if (input_overrun()) return fail("unexpected end of deflate stream");
         refill();
         const uint32_t len = take(16), nlen = take(16);
+        // LEN/NLEN must lie inside the input: read from the zero pad they would pass the check as 0xFFFF/0x0000
+        if (input_overrun()) return fail("unexpected end of deflate stream");
         if ((len ^ nlen) != 0xFFFFu) return fail("stored block length check failed");
         stored_left = len;
         state = kStored;
@@ -198,11 +206,16 @@ bool GzInflater::Impl::read_block_header()
         const int nclen = (int)take(4) + 4;
         if (nlit > 286 || ndist > 30) return fail("too many length or distance symbols");
         uint8_t clens[19] = {0};
+        if (input_overrun()) return fail("unexpected end of deflate stream");
         refill();
         for (int i = 0; i < nclen; ++i) {
-            if (bitcnt < 3) refill();
+            if (bitcnt < 3) {
+                if (input_overrun()) return fail("unexpected end of deflate stream");
+                refill();
+            }
             clens[kClenOrder[i]] = (uint8_t)take(3);
         }
+        if (input_overrun()) return fail("unexpected end of deflate stream");
         uint32_t ctab[128 + 19 * 2];
         if (!build_table(clens, 19, 7, ctab, (int)(sizeof(ctab) / sizeof(ctab[0])), [](int s) { return (uint32_t)s << kValShift; }))
             return fail("invalid code lengths set");
@@ -271,10 +284,8 @@ bool GzInflater::Impl::read_trailer()
 
 // ---- CRC-32 (IEEE 802.3 polynomial, as gzip), slicing by 8 -----------------------------------
 static uint32_t g_crc_table[8][256];
-static bool g_crc_ready = false;
-static void init_crc()
+static void build_crc_tables()
 {
-    if (g_crc_ready) return;
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
@@ -282,7 +293,11 @@ static void init_crc()
     }
     for (uint32_t i = 0; i < 256; ++i)
         for (int t = 1; t < 8; ++t) g_crc_table[t][i] = (g_crc_table[t - 1][i] >> 8) ^ g_crc_table[0][g_crc_table[t - 1][i] & 0xFF];
-    g_crc_ready = true;
+}
+static void init_crc()
+{ // the inflate threads of a paired sample and their CRC followers all come through here
+    static std::once_flag once;
+    std::call_once(once, build_crc_tables);
 }
 static uint32_t crc32_tables(uint32_t c, const uint8_t *p, size_t n) // c and result are the raw (inverted) register
 {
@@ -435,7 +450,7 @@ size_t GzInflater::inflate(uint8_t *out, size_t limit, const uint8_t *window_sta
             s.bitbuf = 0;
             s.bitcnt = 0;
             size_t n = s.stored_left;
-            if ((size_t)(s.in_end - s.in) < n) { s.fail("unexpected end of stored block"); return (size_t)-1; }
+            if (s.in > s.in_end || (size_t)(s.in_end - s.in) < n) { s.fail("unexpected end of stored block"); return (size_t)-1; }
             if (o + n > o_limit) n = o < o_limit ? (size_t)(o_limit - o) : 0;
             memcpy(o, s.in, n);
             o += n;
@@ -555,8 +570,8 @@ extern "C" int mhx_gunzip_buffer(const void *gz, size_t n, void *out, size_t cap
 {
     clear_error();
     if (!gz || !out_n) return fail(MHX_E_ARG, "null argument");
-    // private padded copy of the input (the decoder reads up to 8 bytes past the end)
-    std::vector<uint8_t> in(n + 16, 0);
+    // private padded copy of the input (the decoder's 8-byte refills run past the end)
+    std::vector<uint8_t> in(n + GzInflater::kInputPad, 0);
     memcpy(in.data(), gz, n);
     GzInflater inf;
     inf.set_input(in.data(), n);

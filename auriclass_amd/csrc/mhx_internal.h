@@ -55,7 +55,8 @@ class GzInflater {
     ~GzInflater();
     GzInflater(const GzInflater &) = delete;
     GzInflater &operator=(const GzInflater &) = delete;
-    // the compressed file (all members); 16 readable bytes must follow data[n - 1]
+    static constexpr size_t kInputPad = 64;   // readable (zero) bytes the caller keeps behind the compressed input
+    // the compressed file (all members); kInputPad readable bytes must follow data[n - 1]
     void set_input(const uint8_t *data, size_t n);
     void set_verify_crc(bool on);
     // Deferred checking: inflate() then returns at every member end (the member's last byte is the last byte it

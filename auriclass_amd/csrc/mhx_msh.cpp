@@ -266,6 +266,9 @@ int msh_read_file(const char *path, SketchSet &s)
     if (rl.ok) {
         Reader::Target lst = rd.resolve(rl.seg, rl.word);
         if (lst.ok && lst.kind == 1 && (lst.hi & 7) == 7) {
+            // resolve() accepts a target right behind the segment's last word (legal for an empty object): the tag
+            // word of a composite list must itself be inside
+            if (!rd.in(lst.seg, lst.word, 1)) return fail(MHX_E_FORMAT, "%s: bad reference list", path);
             const uint64_t tag = rd.seg[lst.seg][lst.word];
             const uint32_t count = (uint32_t)(tag >> 2) & 0x3FFFFFFF, ed = (uint32_t)(tag >> 32) & 0xFFFF, ep = (uint32_t)(tag >> 48);
             if (!rd.in(lst.seg, lst.word + 1, (uint64_t)count * (ed + ep)) || ed < 2 || ep < 6)

@@ -124,7 +124,12 @@ extern "C" int mhx_bounds(int k, double p, char *buf, size_t cap, size_t *need)
 {
     clear_error();
     if (k < 1 || k > 32 || !(p > 0.0 && p < 1.0)) return fail(MHX_E_ARG, "bounds: k in 1..32 and 0 < p < 1 required");
-    const std::string t = bounds_text(k, p);
+    std::string t;
+    try {
+        t = bounds_text(k, p);
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_bounds: %s", e.what());
+    }
     if (need) *need = t.size() + 1;
     if (cap == 0) return MHX_OK;
     if (!buf || cap < t.size() + 1) return fail(MHX_E_CAPACITY, "bounds: buffer too small (%zu needed)", t.size() + 1);

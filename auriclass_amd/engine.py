@@ -100,6 +100,8 @@ def load() -> ctypes.CDLL:
     L.mhx_sketcher_threshold.argtypes = [c.c_void_p, u64p]
     L.mhx_sketcher_export.argtypes = [c.c_void_p, c.c_uint64, c.c_void_p, c.c_void_p, c.c_uint32, u32p]
     L.mhx_merge_partials.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint32, c.c_uint32, c.c_void_p, c.c_void_p, u32p]
+    L.mhx_merge_shard_partials.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint32, c.c_int, c.c_uint32, c.c_uint32,
+                                           c.c_void_p, c.c_void_p, u32p]
     L.mhx_dist_batch.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32,
                                  c.c_int, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
     L.mhx_last_dist_kernel_ms.restype = c.c_double
@@ -326,6 +328,23 @@ def merge_partials(hashes: np.ndarray, counts: np.ndarray, s: int, min_mult: int
     n = ctypes.c_uint32(0)
     _check(load().mhx_merge_partials(hashes.ctypes.data, counts.ctypes.data, hashes.size, s, min_mult,
                                      oh.ctypes.data, oc.ctypes.data, ctypes.byref(n)))
+    return oh[:n.value].copy(), oc[:n.value].copy()
+
+
+def merge_shard_partials(hashes: Sequence[np.ndarray], counts: Sequence[np.ndarray], thresholds: Sequence[int], k: int, s: int,
+                         min_mult: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """Merge of the shards' exports (one array pair and one admission threshold per shard) with the exactness
+    rule of the sharded path: EngineError(MHX_E_CAPACITY) when the partials do not determine the union's sketch."""
+    assert len(hashes) == len(counts) == len(thresholds) and len(thresholds) > 0
+    sizes = np.array([len(h) for h in hashes], dtype=np.uint64)
+    allh = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.uint64) for h in hashes]) if len(hashes) else np.zeros(0, np.uint64))
+    allc = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in counts]) if len(counts) else np.zeros(0, np.uint32))
+    thr = np.array([int(x) for x in thresholds], dtype=np.uint64)
+    oh = np.zeros(s, dtype=np.uint64)
+    oc = np.zeros(s, dtype=np.uint32)
+    n = ctypes.c_uint32(0)
+    _check(load().mhx_merge_shard_partials(allh.ctypes.data, allc.ctypes.data, sizes.ctypes.data, thr.ctypes.data, len(thr), k, s,
+                                           min_mult, oh.ctypes.data, oc.ctypes.data, ctypes.byref(n)))
     return oh[:n.value].copy(), oc[:n.value].copy()
 
 

@@ -4,24 +4,41 @@ record-aligned shard, then ONE collective merges the partial results (SURVEY.md 
 
   1. every rank exports all (hash, count) it saw with hash <= its own admission threshold T_r
      (no multiplicity filter, so counts stay summable)
-  2. ONE all-gather of a fixed-size slab per rank: [n, T_r, hashes.., counts..]
+  2. ONE all-gather of a fixed-size slab per rank: [n, T_r, flags, hashes.., counts..]
   3. every rank takes T_min = min_r T_r, drops what lies above it, and merges: sum counts per hash,
-     keep count >= m, first s ascending.
+     keep count >= m, first s ascending (engine.merge_shard_partials = mhx_merge_shard_partials).
+  4. the exactness rule, on gathered data only, so that every rank reaches the same verdict:
+     >= s merged entries qualify below T_min, or no rank has ever rejected a hash (T_min is still
+     the largest hash value) -> done; otherwise :class:`InexactShardedSketch` -- never a short sketch.
+     `sharded_sketch` answers that by sketching every shard again with a 16x admission budget.
 
-Exact for any m: each rank's threshold never drops below the global s-th qualifying hash
-(local counts are lower bounds of global counts), so below T_min every rank's list is complete
-and its counts are exact.  The payload is a few thousand 12-byte entries per rank: latency-bound,
-not link-bound, which is why it is a single collective.
+Why 4 is needed: below T_min every rank's list is complete and its counts exact (a threshold only
+ever falls).  A threshold lowered by the tighten pass sits above s locally qualifying hashes, which
+qualify globally too, so the union has its s entries below T_min.  With a multiplicity filter
+(m > 1; 3 is AuriClass's FASTQ default, /root/reference/auriclass/args.py:128-134) a shard's threshold
+is at first a host-imposed CAP that follows the bytes seen (mhx_engine.cpp, push_device); a shallow
+shard can end with that cap below the global s-th solid hash -- plenty of solid k-mers exist, but above
+T_min, where the other ranks' lists are incomplete.  The payload is a few thousand 12-byte entries per
+rank: latency-bound, not link-bound, which is why it is a single collective.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import engine
+
 U64_MAX = (1 << 64) - 1
+DEVICE_FLAG_MASK = 0xFF   # word [2] of a slab: device flags below, MHX_SLAB_* host-state bits above
+SLAB_BOUNDED = 0x100
+SLAB_ESTABLISHED = 0x200
+
+
+class InexactShardedSketch(engine.EngineError):
+    """The gathered partials cannot decide the sketch of the union (raised on every rank alike)."""
 
 
 def _to_i64(a: np.ndarray) -> torch.Tensor:
@@ -42,13 +59,23 @@ def _gather(t: torch.Tensor) -> List[np.ndarray]:
     return [host[r * t.numel():(r + 1) * t.numel()] for r in range(world)]
 
 
-def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.ndarray, np.ndarray]], s: int, min_mult: int,
-                       merge: Callable[[np.ndarray, np.ndarray, int, int], Tuple[np.ndarray, np.ndarray]],
-                       device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
-    """The exchange step. `export(limit)` -> (hashes, counts) of this rank; `merge` = engine.merge_partials.
+def _merge(parts_h: List[np.ndarray], parts_c: List[np.ndarray], thresholds: List[int], k: int, s: int, min_mult: int
+           ) -> Tuple[np.ndarray, np.ndarray]:
+    try:
+        return engine.merge_shard_partials(parts_h, parts_c, thresholds, k, s, min_mult)
+    except engine.EngineError as e:
+        if e.code == engine.MHX_E_CAPACITY:
+            raise InexactShardedSketch(e.code, e.message) from None
+        raise
+
+
+def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.ndarray, np.ndarray]], k: int, s: int,
+                       min_mult: int, device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
+    """The exchange step. `export(limit)` -> (hashes, counts) of this rank.
     Works on any initialised process group; tensors live on `device` (cuda for nccl, cpu for gloo).
     One collective: an all-gather of one fixed-size slab per rank ([n, threshold, hashes.., counts..],
-    4*s + 4096 entries; a second, exact-size round only if a rank holds more)."""
+    4*s + 4096 entries; a second, exact-size round only if a rank holds more).
+    Raises InexactShardedSketch on every rank when the partials do not determine the union's sketch."""
     hashes, counts = export(local_threshold)
     cap = 4 * s + 4096
     n = len(hashes)
@@ -67,23 +94,20 @@ def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.nd
     if max(sizes) > cap:   # rare: a rank saw more distinct hashes below its threshold than the fixed slab holds
         cap = max(sizes)
         got = _gather(slab(cap))
-    t_min = min(int(g[1:2].view(np.uint64)[0]) for g in got)
-    all_h, all_c = [], []
-    for r, g in enumerate(got):
-        h = g[2:2 + sizes[r]].view(np.uint64)
-        c = g[2 + cap:2 + cap + sizes[r]].astype(np.uint32)
-        keep = h <= np.uint64(t_min)
-        all_h.append(h[keep])
-        all_c.append(c[keep])
-    return merge(np.concatenate(all_h), np.concatenate(all_c), s, min_mult)
+    thresholds = [int(g[1:2].view(np.uint64)[0]) for g in got]
+    all_h = [g[2:2 + sizes[r]].view(np.uint64) for r, g in enumerate(got)]
+    all_c = [g[2 + cap:2 + cap + sizes[r]].astype(np.uint32) for r, g in enumerate(got)]
+    return _merge(all_h, all_c, thresholds, k, s, min_mult)
 
 
-def exchange_and_merge_device(sk, s: int, min_mult: int, merge, device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
+def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
     """The same exchange with the partial results staying on the GPU until they have been gathered:
     `sk.export_slab` writes [n, T_r, flags, hashes.., counts..] into a device tensor (one kernel, no
     PCIe), the slabs are all-gathered by RCCL, ONE device-to-host copy brings all of them over, and the
     merge runs on the host as before.  Falls back to exchange_and_merge (on every rank alike, the decision
-    only uses gathered data) when a slab overflowed or a shard never tightened its threshold."""
+    only uses gathered data) when a slab overflowed or a 64-bit shard never tightened its threshold
+    (the hash value 2^64-1 has no place in a slab).  Same exactness rule, same exception."""
+    k, s, min_mult = sk.k, sk.s, sk.m
     cap = 4 * s + 4096
     slab = torch.empty(3 + cap + cap // 2, dtype=torch.int64, device=device)
     sk.export_slab(slab.data_ptr(), cap)
@@ -92,20 +116,46 @@ def exchange_and_merge_device(sk, s: int, min_mult: int, merge, device: torch.de
     thresholds = [int(g[1:2].view(np.uint64)[0]) for g in got]
     flags = 0
     for g in got:
-        flags |= int(g[2])
+        flags |= int(g[2]) & DEVICE_FLAG_MASK
     if flags:
         raise RuntimeError(f"device flags {flags:#x} raised during sketching (table full / malformed FASTQ)")
     if max(sizes) > cap or max(thresholds) == U64_MAX:
-        return exchange_and_merge(sk.threshold(), sk.export, s, min_mult, merge, device)
-    t_min = min(thresholds)
-    all_h, all_c = [], []
-    for r, g in enumerate(got):
-        h = g[3:3 + sizes[r]].view(np.uint64)
-        c = g[3 + cap:].view(np.uint32)[:sizes[r]]
-        keep = h <= np.uint64(t_min)
-        all_h.append(h[keep])
-        all_c.append(c[keep])
-    return merge(np.concatenate(all_h), np.concatenate(all_c), s, min_mult)
+        return exchange_and_merge(sk.threshold(), sk.export, k, s, min_mult, device)
+    all_h = [g[3:3 + sizes[r]].view(np.uint64) for r, g in enumerate(got)]
+    all_c = [g[3 + cap:].view(np.uint32)[:sizes[r]] for r, g in enumerate(got)]
+    return _merge(all_h, all_c, thresholds, k, s, min_mult)
+
+
+def sharded_sketch(push: Callable[[object], None], k: int, s: int, min_mult: int, expected_bytes: int, device: torch.device,
+                   first: Optional[object] = None, max_budget_scale: int = 4096,
+                   sketcher_factory: Optional[Callable[[int], object]] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Sketch of the union of all ranks' shards, exact for any m, on every rank.
+    `push(sk)` feeds this rank's shard into the engine.Sketcher it is given (it may be called again:
+    every retry sketches the shard afresh).  `first`: a sketcher that already holds the shard (budget 1).
+    `device`: where the collective's tensors live (cuda -> RCCL with device-resident slabs, cpu -> gloo).
+    When the exchange reports InexactShardedSketch -- on all ranks at once -- every rank repeats with 16x
+    the admission budget and candidate table (what mhx_sketch_files does by itself on one GPU); past
+    `max_budget_scale` the exception is passed on.  `sketcher_factory(budget_scale)` replaces engine.Sketcher
+    (the CPU tests of the decision logic use it)."""
+    scale, sk, own = 1, first, False
+    while True:
+        if sk is None:
+            sk = (sketcher_factory(scale) if sketcher_factory else
+                  engine.Sketcher(k, s, min_mult, expected_bytes=expected_bytes, budget_scale=scale))
+            own = True
+            push(sk)
+        try:
+            if device.type == "cuda":
+                return exchange_and_merge_device(sk, device)
+            return exchange_and_merge(sk.threshold(), sk.export, k, s, min_mult, device)
+        except InexactShardedSketch:
+            if scale * 16 > max_budget_scale:
+                raise
+            scale *= 16
+        finally:
+            if own:
+                sk.close()
+            sk, own = None, False
 
 
 def shard_bounds(n_records: int, world: int, rank: int) -> Tuple[int, int]:

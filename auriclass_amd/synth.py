@@ -92,3 +92,24 @@ def make_fastq(genome: np.ndarray, n_reads: int, read_len: int = 150, seed: int 
         rec[:, 14 + read_len:14 + 2 * read_len] = ord("I")
         rec[:, 14 + 2 * read_len] = ord("\n")
     return out
+
+
+def make_fastq_range(genome: np.ndarray, lo: int, hi: int, read_len: int = 150, seed0: int = 43, block_reads: int = 10_000_000,
+                     device: str = "cpu") -> torch.Tensor:
+    """Reads [lo, hi) of the C4 read set: block b = reads [b * block_reads, (b + 1) * block_reads) drawn
+    with seed seed0 + b, so the union over any record-aligned partition is the same byte stream whatever the number of
+    ranks.  A block is generated whole and the wanted part kept (the draws of one seed are not addressable by position)."""
+    rb = record_bytes(read_len)
+    out = torch.empty((hi - lo) * rb, dtype=torch.uint8, device=torch.device(device))
+    pos = 0
+    for b in range(lo // block_reads, (max(hi, lo + 1) - 1) // block_reads + 1):
+        b0 = b * block_reads
+        a, e = max(lo, b0), min(hi, b0 + block_reads)
+        if e <= a:
+            continue
+        blk = make_fastq(genome, block_reads, read_len, seed=seed0 + b, device=device, first_index=b0)
+        n = (e - a) * rb
+        out[pos:pos + n] = blk[(a - b0) * rb:(e - b0) * rb]
+        pos += n
+        del blk
+    return out

@@ -2,12 +2,16 @@
 """Headline benchmark: Gbases/s sketched (k=21, s=1000) on synthetic FASTQ resident in HBM.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...                      (starts N ranks by itself, one per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one whole sketch job over this rank's 10 M x 150 bp reads (BASELINE.json configs[2]):
-reset the device table, run the tile kernels over the FASTQ bytes, pull the final sorted
-sketch to host memory; with N > 1 also the cross-rank exchange + merge (weak scaling: every
-rank owns its own 10 M reads, the answer is the sketch of the union).
+One step = one whole sketch job over this rank's reads: reset the device table, run the tile kernels
+over the FASTQ bytes, pull the final sorted sketch to host memory; with N > 1 also the cross-rank
+exchange + merge with its exactness rule (auriclass_amd.multigpu.sharded_sketch).
+  weak scaling (default):      every rank owns --reads reads (10 M x 150 bp, BASELINE.json configs[2]),
+                               the answer is the sketch of the union;
+  strong scaling (--total-reads T): T reads in all, rank r owns records [r*T/N, (r+1)*T/N)
+                               (BASELINE.json configs[3] / SURVEY 8(d) C4: --total-reads 80000000).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -102,23 +106,57 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (weak scaling)")
+    ap.add_argument("--total-reads", type=int, default=0, help="reads in all, split over the GPUs (strong scaling); 0 = off")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--s", type=int, default=1000)
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--genome", type=int, default=12_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
-    ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="host cores of the CPU leg; 0 = min(cores this process may run on, 16 = the CPU share of a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = nproc
+    if args.cpu_cores <= 0:
+        args.cpu_cores = max(1, min(usable, 16))
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started as plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched
+        # HIP (importing torch and counting devices does not), and it never will: the N ranks are fresh child
+        # processes of torch.distributed.run, one per GPU, and their JSON line is passed through.
+        import socket
+        import subprocess
+
+        if torch.cuda.device_count() < args.gpus and os.environ.get("MHX_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible "
+                             "(MHX_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    strong = args.total_reads > 0
+    if strong:
+        lo, hi = multigpu.shard_bounds(args.total_reads, world, rank)
+        args.reads = hi - lo
+        first_read, seed = lo, None   # C4: seeds 43.., 10 M reads each (synth.make_fastq_range)
+    else:
+        first_read, seed = rank * args.reads, 43 + rank
     # one process per GPU; MHX_DIST_BACKEND=gloo lets several ranks rehearse on a 1-GPU box
     backend = os.environ.get("MHX_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -138,21 +176,26 @@ def main() -> None:
 
     # ---- synthetic input, resident in HBM before anything is timed -------------------------
     genome = synth.make_genome(args.genome, seed=42)
-    fq = synth.make_fastq(genome, args.reads, args.read_len, seed=43 + rank, device=str(dev),
-                          first_index=rank * args.reads)
+    if strong:   # the same 80 M-read stream whatever N is: rank r holds records [lo, hi) of it
+        fq = synth.make_fastq_range(genome, first_read, first_read + args.reads, args.read_len, device=str(dev))
+    else:
+        fq = synth.make_fastq(genome, args.reads, args.read_len, seed=seed, device=str(dev), first_index=first_read)
     torch.cuda.synchronize()
     nbytes = fq.numel()
     bases = args.reads * args.read_len
     sk = engine.Sketcher(args.k, args.s, args.m, expected_bytes=nbytes)
 
+    def push(target):
+        target.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
+
     def step():
         sk.reset()
-        sk.push_device(fq.data_ptr(), nbytes, engine.FMT_FASTQ4)
+        push(sk)
         if not use_dist:
             return sk.finish()
-        if comm_dev.type == "cuda":   # RCCL: the partial results stay on the GPU until they have been gathered
-            return multigpu.exchange_and_merge_device(sk, args.s, args.m, engine.merge_partials, comm_dev)
-        return multigpu.exchange_and_merge(sk.threshold(), sk.export, args.s, args.m, engine.merge_partials, comm_dev)
+        # RCCL: the partial results stay on the GPU until they have been gathered (gloo: host slabs); if the gathered
+        # partials do not determine the union's sketch every rank re-sketches with a wider budget, inside the step
+        return multigpu.sharded_sketch(push, args.k, args.s, args.m, nbytes, comm_dev, first=sk)
 
     def barrier():
         torch.cuda.synchronize()
@@ -173,7 +216,13 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * bases / (elapsed / args.steps) / 1e9
+    total_bases = bases
+    if use_dist:   # ranks may hold different numbers of reads (strong scaling with a remainder)
+        tb = torch.tensor([bases], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = int(tb.item())
+    value = total_bases / (elapsed / args.steps) / 1e9
+    ranks_in_group = dist.get_world_size() if use_dist else 1
 
     # ---- dominant kernel: HIP events on the engine's stream around every tile-kernel launch --
     roofline = None
@@ -215,6 +264,7 @@ def main() -> None:
             sample = fq[: n_s * rb].cpu().numpy()
             want, cpu_s, cores = cpu_baseline_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
             cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": cores,
+                            "nproc": nproc, "usable_cores": usable,
                             "per_core": round(n_s * args.read_len / cpu_s / 1e9 / max(1, cores), 5),
                             "kind": "port",
                             "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input in {cores} record "
@@ -223,7 +273,7 @@ def main() -> None:
             stock = stock_mash_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
             if stock is not None:   # a real mash on this host: that is the baseline to quote
                 cpu_baseline = {"value": round(n_s * args.read_len / stock[0] / 1e9, 5), "unit": "Gbases/s", "cores": stock[1],
-                                "kind": "reference",
+                                "nproc": nproc, "usable_cores": usable, "kind": "reference",
                                 "sample": f"stock mash sketch -r -m {args.m} -k {args.k} -s {args.s} on the first {n_s} reads in "
                                           f"{stock[1]} record shards, one process each; wall {stock[0]:.1f} s; C-oracle port on the "
                                           f"same sample: {cpu_baseline['value']} Gbases/s on {cpu_baseline['cores']} cores"}
@@ -237,10 +287,14 @@ def main() -> None:
         line = {
             "metric": "Gbases/s sketched (k=21, s=1000)", "value": round(value, 3), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic FASTQ {args.reads} x {args.read_len} bp reads per GPU from a "
-                                   f"{args.genome} bp genome, 0.5% substitutions, {nbytes} bytes resident in HBM",
-                       "k": args.k, "s": args.s, "min_multiplicity": args.m,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": (f"synthetic FASTQ {args.total_reads} x {args.read_len} bp reads in all, record-sharded over "
+                                    f"{world} GPU(s) ({args.reads} on rank 0, {nbytes} bytes resident in its HBM)" if strong else
+                                    f"synthetic FASTQ {args.reads} x {args.read_len} bp reads per GPU from a "
+                                    f"{args.genome} bp genome, 0.5% substitutions, {nbytes} bytes resident in HBM"),
+                       "k": args.k, "s": args.s, "min_multiplicity": args.m, "total_bases": total_bases,
+                       "ranks": ranks_in_group, "collective": (backend if use_dist else None),
                        "parallelism": "1 process/GPU, record shards, all-gather of partial sketches" if world > 1 else "1 GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "parity_on_sample": parity, "sketch_len": int(len(result[0])),

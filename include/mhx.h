@@ -21,6 +21,12 @@
  * (including the terminating NUL), then call again with a buffer of that size.
  * All compute runs on the GPU selected by mhx_init(); there is no CPU fallback:
  * without a usable HIP device every compute entry point fails with MHX_E_NO_DEVICE.
+ *
+ * One device, one caller: the engine state (device, stream, staging buffers) is a process-wide
+ * singleton, as `mash` was one process per sample (docs/running_analysis.md:47-59 of the reference).
+ * mhx_init(d) binds the process to GPU d; a second mhx_init with another device tears the first
+ * engine down.  Calls are not thread-safe against each other (only mhx_last_error is thread-local).
+ * Several GPUs = several processes, one per GPU (auriclass_amd/multigpu.py; bench.py --gpus N).
  */
 #ifndef MHX_H
 #define MHX_H
@@ -127,6 +133,20 @@ int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint
 int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t cap);
 int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s,
                        uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
+/* bits a shard adds to word [2] of its slab besides the device flags (diagnostics of the m > 1 phase) */
+#define MHX_SLAB_BOUNDED 0x100      /* a host-imposed cap has limited the shard's threshold at least once  */
+#define MHX_SLAB_ESTABLISHED 0x200  /* the threshold has since been lowered from solid (count >= m) hashes */
+/* The merge step of the sharded path together with its exactness rule: hashes/counts are the shards'
+ * exports back to back (shard r contributes shard_n[r] entries, all <= shard_threshold[r]).  Entries above
+ * T_min = min_r shard_threshold[r] are dropped (only below it is every shard's list complete), counts of equal
+ * hashes are summed, count >= min_mult kept, first s returned.  If fewer than s qualify although some shard
+ * has rejected hashes (T_min below the largest hash value of this k), the union cannot be decided from these
+ * partials: MHX_E_CAPACITY -- every rank sketches its shard again with a larger budget_scale
+ * (mhx_sketcher_create_scaled) and the exchange is repeated; a short sketch is never returned in that case.
+ * SURVEY.md 8(e); the m = 3 default of /root/reference/auriclass/args.py:128-134 is what makes this matter. */
+int mhx_merge_shard_partials(const uint64_t *hashes, const uint32_t *counts, const uint64_t *shard_n,
+                             const uint64_t *shard_threshold, uint32_t n_shards, int k, uint32_t s,
+                             uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
 
 /* Batched all-vs-refs `mash dist` arithmetic on the device: q and r are row-major
  * [n][stride] ascending unique hash lists with q_len/r_len valid entries each.

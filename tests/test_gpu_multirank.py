@@ -46,7 +46,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir):
     sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
     sk.sync()
     assert sk.record_count() == hi - lo
-    got_h, got_c = multigpu.exchange_and_merge(sk.threshold(), sk.export, s, m, engine.merge_partials, torch.device("cpu"))
+    got_h, got_c = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
     np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
     sk.close()
@@ -82,7 +82,7 @@ def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
     torch.cuda.synchronize()
     sk = engine.Sketcher(k, s, m, expected_bytes=fq.numel())
     sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)
-    got_h, got_c = multigpu.exchange_and_merge_device(sk, s, m, engine.merge_partials, torch.device("cuda", 0))
+    got_h, got_c = multigpu.exchange_and_merge_device(sk, torch.device("cuda", 0))
     ref_h, ref_c = sk.finish()
     np.save(os.path.join(out_dir, "slab_h.npy"), got_h)
     np.save(os.path.join(out_dir, "slab_c.npy"), got_c)
@@ -92,7 +92,7 @@ def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
     sk2 = engine.Sketcher(k, s, m, expected_bytes=0)
     rb = synth.record_bytes(READ_LEN)
     sk2.push_device(fq.data_ptr(), 5 * rb, engine.FMT_FASTQ4)
-    tiny_h, _ = multigpu.exchange_and_merge_device(sk2, s, m, engine.merge_partials, torch.device("cuda", 0))
+    tiny_h, _ = multigpu.exchange_and_merge_device(sk2, torch.device("cuda", 0))
     want_h, _ = sk2.finish()
     assert np.array_equal(tiny_h, want_h)
     sk.close()
@@ -142,7 +142,7 @@ def _byte_range_worker(rank, world, port, k, s, m, out_dir):
     torch.cuda.synchronize()
     sk = engine.Sketcher(k, s, m, expected_bytes=shard.numel())
     sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
-    got_h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, s, m, engine.merge_partials, torch.device("cpu"))
+    got_h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
     np.save(os.path.join(out_dir, f"b{rank}.npy"), got_h)
     sk.close()
     dist.destroy_process_group()
@@ -160,3 +160,126 @@ def test_byte_range_shards_of_a_ragged_fastq(tmp_path):
     want, _ = ref.finish()
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"b{r}.npy"), want), f"rank {r}"
+
+
+# ---- the exactness rule of the sharded path (m > 1 protocol) -------------------------------
+# Inputs on which a shard's admission threshold ends as a host-imposed cap below the global s-th solid hash:
+# the plain exchange must refuse them on EVERY rank (never a short sketch), and multigpu.sharded_sketch must
+# come back with the oracle's sketch on every rank after sketching the shards again with a wider budget.
+HARD_CASES = {
+    # name: (genome bp, reads, k, s, m)
+    "low_coverage_m3": (60_000_000, 120_000, 21, 20_000, 3),   # coverage 0.3: the input of the single-GPU retry test
+    "m8_at_40x": (300_000, 80_000, 21, 2_000, 8),              # m >= 8 is the regime DESIGN 3.2 sends to the retry
+    "fewer_than_s_solid": (2_000_000, 20_000, 21, 50_000, 3),  # 1.5x coverage: < s solid k-mers in total
+}
+
+
+def _hard_input(name):
+    glen, n_reads, *_ = HARD_CASES[name]
+    genome = synth.make_genome(glen, seed=77)
+    return synth.make_fastq(genome, n_reads, READ_LEN, seed=78, device="cpu").numpy()
+
+
+def _hard_worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auriclass_amd import engine
+
+    engine.init(0)
+    _, n_reads, k, s, m = HARD_CASES[name]
+    fq = _hard_input(name)
+    rb = synth.record_bytes(READ_LEN)
+    lo, hi = multigpu.shard_bounds(n_reads, world, rank)
+    shard = torch.from_numpy(fq[lo * rb:hi * rb]).to("cuda:0")
+    torch.cuda.synchronize()
+    attempts = []
+
+    def push(sk):
+        attempts.append(1)
+        sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+
+    # 1. the bare exchange on budget-1 sketchers: exact or refused, on every rank alike
+    sk = engine.Sketcher(k, s, m, expected_bytes=shard.numel())
+    push(sk)
+    try:
+        h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
+        np.save(os.path.join(out_dir, f"plain{rank}.npy"), h)
+    except multigpu.InexactShardedSketch:
+        np.save(os.path.join(out_dir, f"plain{rank}.npy"), np.zeros(1, np.float64))   # marker: refused
+    sk.close()
+    # 2. the retrying driver
+    got_h, got_c = multigpu.sharded_sketch(push, k, s, m, shard.numel(), torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
+    np.save(os.path.join(out_dir, f"a{rank}.npy"), np.array([len(attempts)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", sorted(HARD_CASES))
+def test_sharded_sketch_is_exact_or_refused_never_short(tmp_path, name, world):
+    from oracle import mash_oracle as mo
+
+    _, n_reads, k, s, m = HARD_CASES[name]
+    mp.spawn(_hard_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(_hard_input(name).tobytes())
+    want, want_c = ref.finish()
+    if name == "fewer_than_s_solid":
+        assert 0 < len(want) < s
+    else:
+        assert len(want) == s
+    refused = []
+    for r in range(world):
+        plain = np.load(tmp_path / f"plain{r}.npy")
+        refused.append(plain.dtype == np.float64)
+        if not refused[-1]:
+            assert np.array_equal(plain, want), f"rank {r}: the bare exchange returned a sketch that is not the oracle's"
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), want_c), f"rank {r}"
+    assert len(set(refused)) == 1, "ranks disagree on the verdict"
+    attempts = {int(np.load(tmp_path / f"a{r}.npy")[0]) for r in range(world)}
+    assert len(attempts) == 1, "ranks retried a different number of times"
+    if refused[0]:
+        assert attempts.pop() >= 3   # 1 (bare) + >= 2 inside sharded_sketch
+
+
+def _nccl_hard_worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from auriclass_amd import engine
+
+    engine.init(0)
+    _, n_reads, k, s, m = HARD_CASES[name]
+    fq = torch.from_numpy(_hard_input(name)).to("cuda:0")
+    torch.cuda.synchronize()
+    attempts = []
+
+    def push(sk):
+        attempts.append(1)
+        sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)
+
+    got_h, got_c = multigpu.sharded_sketch(push, k, s, m, fq.numel(), torch.device("cuda", 0))
+    np.save(os.path.join(out_dir, "h.npy"), got_h)
+    np.save(os.path.join(out_dir, "a.npy"), np.array([len(attempts)]))
+    dist.destroy_process_group()
+
+
+def test_device_slab_exchange_retries_a_capped_shard(tmp_path):
+    """The slab form (RCCL, 1-rank group on the box's one GPU) carries the same rule: the low-coverage input is
+    refused at budget 1 and comes back exact from the retry."""
+    from oracle import mash_oracle as mo
+
+    name = "low_coverage_m3"
+    _, n_reads, k, s, m = HARD_CASES[name]
+    mp.spawn(_nccl_hard_worker, args=(1, _free_port(), name, str(tmp_path)), nprocs=1, join=True)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(_hard_input(name).tobytes())
+    want, _ = ref.finish()
+    assert np.array_equal(np.load(tmp_path / "h.npy"), want)
+    assert int(np.load(tmp_path / "a.npy")[0]) >= 2

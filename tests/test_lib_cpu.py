@@ -3,6 +3,9 @@ its host-only pieces (bounds table, .msh container, sniffers) match the referenc
 and every compute entry point refuses to run without a GPU (no CPU fallback)."""
 import ctypes
 
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -167,6 +170,69 @@ def test_gunzip_rejects_corrupt_streams(lib):
         except engine.EngineError:
             flipped += 1
     assert flipped >= 30
+
+
+def test_gunzip_never_reads_stored_block_lengths_from_the_pad(lib):
+    """a file that ends in a stored-block header `01 FF FF` used to take NLEN = 0 from the zero pad, pass the
+    LEN ^ NLEN test with LEN = 65535 and memcpy 65535 bytes from beyond the compressed buffer."""
+    hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3])
+    stored = bytes([0x00, 0x04, 0x00, 0xFB, 0xFF]) + b"ACGT"
+    for tail in (b"\x01\xff\xff", b"\x01\xff", b"\x01", b"\x00\xff\xff", b"\x01\x00\x00"):
+        z = hdr + stored + tail
+        z += b"\0" * max(0, 18 - len(z))
+        with pytest.raises(engine.EngineError):
+            engine.gunzip(z)
+    # a complete little file of the same shape is still fine
+    import zlib
+    body = stored[:0] + bytes([0x01, 0x04, 0x00, 0xFB, 0xFF]) + b"ACGT"
+    z = hdr + body + zlib.crc32(b"ACGT").to_bytes(4, "little") + (4).to_bytes(4, "little")
+    assert engine.gunzip(z) == b"ACGT"
+
+
+def test_gunzip_header_truncation_sweep(lib):
+    """Every prefix of a multi-block .gz (cut inside the member header, the HLIT/HDIST/HCLEN fields, the code-length
+    code, the length runs, the data, the trailer) is refused or -- cut between members -- decodes to a prefix; none
+    crashes.  The same sweep runs under AddressSanitizer in test_inflate_under_address_sanitizer."""
+    rng = np.random.default_rng(9)
+    text = _fastq_like(rng, 1500)
+    z = _gz(text[:200_000], 6) + _gz(text[200_000:], 1)
+    first = len(_gz(text[:200_000], 6))
+    cuts = list(range(0, 700)) + list(range(700, len(z), 211)) + list(range(len(z) - 30, len(z)))
+    for cut in cuts:
+        try:
+            out = engine.gunzip(z[:cut])
+        except engine.EngineError:
+            continue
+        # accepted prefixes: nothing at all (shorter than a member), or exactly the first member
+        assert out == b"" and cut < 18 or (out == text[:200_000] and first <= cut < first + 18), cut
+
+
+def test_inflate_under_address_sanitizer(tmp_path):
+    """CPU ASan/UBSan build of mhx_inflate.cpp with tests/asan/inflate_fuzz.cpp: exact-size input blocks (n + kInputPad),
+    the crafted stored-block tails, a truncation sweep and mutation fuzzing.  Any out-of-bounds access aborts."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "inflate_fuzz"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+           str(root / "tests" / "asan" / "inflate_fuzz.cpp"), str(root / "auriclass_amd" / "csrc" / "mhx_inflate.cpp"), "-o", str(exe), "-lpthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr and "cannot find" in b.stderr:
+        pytest.skip("no sanitizer runtime on this host")
+    assert b.returncode == 0, b.stderr[-2000:]
+    rng = np.random.default_rng(12)
+    text = _fastq_like(rng, 400)
+    seeds = {"dyn.gz": _gz(text, 6), "fixed_stored.gz": _gz(text[:3000], 0) + _gz(b"ACGT" * 50, 9, filename="x.fq")}
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for i, (name, z) in enumerate(seeds.items()):
+        p = tmp_path / name
+        p.write_bytes(z)
+        r = subprocess.run([str(exe), str(p), "1500", str(17 + i)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-500:], r.stderr[-3000:])
+        assert r.stdout.startswith("ok ")
 
 
 def test_msh_writer_equals_the_oracle_writer_on_random_containers(lib, tmp_path):

@@ -55,7 +55,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir):
         keep = vals <= np.uint64(limit)
         return vals[keep], cnts[keep]
 
-    got_h, got_c = multigpu.exchange_and_merge(thr, export, s, m, engine.merge_partials, torch.device("cpu"))
+    got_h, got_c = multigpu.exchange_and_merge(thr, export, k, s, m, torch.device("cpu"))
     np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
     dist.destroy_process_group()
@@ -80,6 +80,102 @@ def test_exchange_and_merge_equals_single_sketch(tmp_path, world, k, s, m):
         assert np.array_equal(got, want), f"rank {r}"
         cnt = np.load(tmp_path / f"c{r}.npy")
         assert cnt.min() >= m
+
+
+class _FakeSketcher:
+    """Stands where engine.Sketcher stands in multigpu.sharded_sketch: the shard's exact (hash, count) table with a
+    CAPPED admission threshold, the cap widening with the budget scale as the engine's does."""
+
+    def __init__(self, vals, cnts, cap):
+        self.vals, self.cnts, self.cap = vals, cnts, cap
+
+    def threshold(self):
+        return self.cap
+
+    def export(self, limit):
+        keep = self.vals <= np.uint64(min(limit, self.cap))
+        return self.vals[keep], self.cnts[keep]
+
+    def close(self):
+        pass
+
+
+def _capped_worker(rank, world, port, k, s, m, n_reads, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    genome = synth.make_genome(30_000, seed=9)
+    fq = synth.make_fastq(genome, n_reads, 100, seed=10, device="cpu").numpy().tobytes()
+    recs = [fq[i:i + synth.record_bytes(100)].split(b"\n")[1] for i in range(0, len(fq), synth.record_bytes(100))]
+    lo, hi = multigpu.shard_bounds(len(recs), world, rank)
+    vals, cnts, _ = _local_partial(recs[lo:hi], k, s, m)
+    # rank 0's cap lies where far fewer than s globally solid hashes exist below it; budget x16 lifts it, x256 removes it
+    base_cap = U64_MAX // 400 if rank == 0 else U64_MAX // 3
+    made = []
+
+    def factory(scale):
+        made.append(scale)
+        return _FakeSketcher(vals, cnts, U64_MAX if scale >= 256 else min(U64_MAX, base_cap * scale))
+
+    # the bare exchange must refuse on every rank
+    f = factory(1)
+    try:
+        multigpu.exchange_and_merge(f.threshold(), f.export, k, s, m, torch.device("cpu"))
+        verdict = 0
+    except multigpu.InexactShardedSketch:
+        verdict = 1
+    got_h, got_c = multigpu.sharded_sketch(lambda sk: None, k, s, m, 0, torch.device("cpu"), sketcher_factory=factory)
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
+    np.save(os.path.join(out_dir, f"v{rank}.npy"), np.array([verdict] + made))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_capped_shard_is_refused_on_every_rank_and_the_retry_is_exact(tmp_path, world):
+    """Decision logic of the sharded path without a GPU: one rank's threshold is a cap below the union's s-th solid
+    hash.  Every rank must raise InexactShardedSketch from the bare exchange (same gathered data, same verdict) and
+    multigpu.sharded_sketch must widen the budget on all ranks in lockstep until the result is the oracle's."""
+    from oracle import mash_oracle as mo
+
+    engine.build()
+    k, s, m, n_reads = 21, 500, 3, 3000
+    mp.spawn(_capped_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path)), nprocs=world, join=True)
+    genome = synth.make_genome(30_000, seed=9)
+    fq = synth.make_fastq(genome, n_reads, 100, seed=10, device="cpu").numpy().tobytes()
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(fq)
+    want, _ = ref.finish()
+    assert len(want) == s
+    scales = set()
+    for r in range(world):
+        v = np.load(tmp_path / f"v{r}.npy")
+        assert v[0] == 1, f"rank {r} accepted partials that do not determine the sketch"
+        scales.add(tuple(v[1:].tolist()))
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
+    assert len(scales) == 1 and len(next(iter(scales))) >= 3, scales   # bare + >= 2 attempts, identical on all ranks
+
+
+def test_merge_shard_partials_rule():
+    """mhx_merge_shard_partials: entries above T_min are dropped; short results are accepted only when no shard
+    has ever rejected a hash (T_min at the largest value of this hash width)."""
+    engine.build()
+    a = np.array([5, 10, 20, 30], np.uint64)
+    b = np.array([10, 15, 30, 40], np.uint64)
+    ones = np.ones(4, np.uint32)
+    # complete shards: short sketch is fine
+    h, c = engine.merge_shard_partials([a, b], [ones, ones], [U64_MAX, U64_MAX], 21, 10, 2)
+    assert h.tolist() == [10, 30] and c.tolist() == [2, 2]
+    # T_min = 25: only 10 qualifies below it, s = 1 is satisfied, s = 2 is not
+    h, _ = engine.merge_shard_partials([a[:3], b], [ones[:3], ones], [25, U64_MAX], 21, 1, 2)
+    assert h.tolist() == [10]
+    with pytest.raises(engine.EngineError) as e:
+        engine.merge_shard_partials([a[:3], b], [ones[:3], ones], [25, U64_MAX], 21, 2, 2)
+    assert e.value.code == engine.MHX_E_CAPACITY
+    # 32-bit hashes (k <= 16): the untouched threshold is 2^32 - 1
+    h, _ = engine.merge_shard_partials([a, b], [ones, ones], [0xFFFFFFFF, 0xFFFFFFFF], 16, 10, 2)
+    assert h.tolist() == [10, 30]
+    with pytest.raises(engine.EngineError):
+        engine.merge_shard_partials([a, b], [ones, ones], [0xFFFFFFFE, 0xFFFFFFFF], 16, 10, 2)
 
 
 def test_shard_bounds_cover_everything_once():
