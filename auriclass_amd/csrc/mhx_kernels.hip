@@ -247,8 +247,12 @@ template <int K> static hipError_t launch_k(int fmt, const HashArgs &a, hipStrea
     return hipGetLastError();
 }
 
+#ifdef MHX_ONLY_K   // experiment / ISA-study builds: one k-mer size
+#define MHX_K_LIST(X) X(MHX_ONLY_K)
+#else
 #define MHX_K_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
     X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#endif
 
 bool hash_k_supported(int k) { return k >= 1 && k <= 32; }
 

@@ -26,21 +26,45 @@ struct uint4 { uint32_t x, y, z, w; };
 
 #include "mhx_device_consts.h"
 
+#ifdef MHX_EXPECT
+#define MHX_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define MHX_UNLIKELY(x) (x)
+#endif
+
 namespace mhx {
 
+constexpr int kMapWords = (kTileBytes + kHaloBytes) / 32 + 2; // words of a 1-bit-per-byte map of tile + halo (+2 look-ahead)
 struct TileSmem {
     uint4 bytes[(kTileBytes + kHaloBytes) / 16];      // staged stream bytes
-    uint32_t good[(kTileBytes + kHaloBytes) / 32 + 2]; // 1 bit per byte: usable base
+#ifndef MHX_LDS_ALIAS
+    uint32_t good[kMapWords];                          // 1 bit per byte: usable base
+#endif
     uint32_t valid[kGroupsPerTile / 4];                // byte g = valid-start mask of group g
+#ifdef MHX_LDS_ALIAS
+    // One area, three tenants with disjoint lifetimes: the newline map (classify -> good-map phase) and the
+    // good-base map (good-map phase -> valid starts) side by side, then the work list (compaction -> hash loop).
+    union {
+        uint16_t list[kGroupsPerTile];
+        uint32_t maps[2 * kMapWords];
+    };
+#else
     uint16_t list[kGroupsPerTile];                     // compacted work list (group ids)
+#endif
     uint32_t cnt[16];                                  // wave partials of the two workgroup scans
     uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
 };
 
 // The newline bit map of the tile lives in the (not yet used) work-list area between the classify
 // and the good-map phases: 1 bit per byte, kTileBytes/32 + 2 words.
+#ifdef MHX_LDS_ALIAS
+MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return sm.maps; }
+MHX_HD uint32_t *tile_good(TileSmem &sm) { return sm.maps + kMapWords; }
+#else
 static_assert(sizeof(uint16_t) * kGroupsPerTile >= sizeof(uint32_t) * (kTileBytes / 32 + 2), "nl map must fit the list area");
 MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return reinterpret_cast<uint32_t *>(sm.list); }
+MHX_HD uint32_t *tile_good(TileSmem &sm) { return sm.good; }
+#endif
 
 // per-thread state carried between phases (registers on the GPU)
 struct ThreadState {
@@ -73,6 +97,7 @@ MHX_HD uint32_t perm_lut(uint32_t lut, uint32_t sel)
 // byte lands on one of the four as well and is exposed by the comparison with the table entry
 MHX_HD uint32_t base_index(uint32_t u) { return (u >> 1) & 0x03030303u; }
 constexpr uint32_t kLutBase = 0x47544341u; // index -> 'A','C','T','G'
+constexpr uint32_t kLutComp = 0x43414754u; // index -> complement: 'T','G','A','C'
 
 // low 32 bits of {hi:lo} >> (8 * byte_shift), byte_shift in 0..3.  On the device this must be
 // the v_alignbyte/v_alignbit instruction itself: written as a C shift-or, LLVM turns the
@@ -92,6 +117,14 @@ MHX_HD uint32_t opaque(uint32_t v)
     asm volatile("" : "+v"(v));
 #endif
     return v;
+}
+// nothing is scheduled across this point (keeps the eight windows of a group from being interleaved, which
+// costs more registers than the overlap is worth)
+MHX_HD void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
 { // bit_shift in 0..31
@@ -224,15 +257,44 @@ template <int K, int NWD> MHX_HD void run_starts(const uint32_t (&w)[NWD + 1], u
 }
 
 // ---- MurmurHash3_x64_128, seed 42, first 8 output bytes (mash getHash) ----------------
-MHX_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// 64-bit values are handled so that hipcc keeps each step in its cheapest form on gfx950:
+//  * a product is made opaque before it is rotated: left to itself the compiler turns rotl(k * c, r) into a SECOND
+//    64x64 multiplication by (c << r) plus the shifted high word (10 instructions where 4 + 2 do);
+//  * rotations and the fmix shift-xors are written on the 32-bit halves (2 v_alignbit / v_lshrrev + v_xor);
+//  * h * 5 + c is one v_mad_u64_u32 for the low word and a shift-add for the high word.
+MHX_HD uint64_t opaque64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
+MHX_HD uint64_t make64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+template <int R> MHX_HD uint64_t rotl64(uint64_t x)
+{
+    static_assert(R > 0 && R < 64 && R != 32, "rotation amount");
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (R < 32) return make64(funnel_bits(lo, hi, 32 - R), funnel_bits(hi, lo, 32 - R));
+    return make64(funnel_bits(hi, lo, 64 - R), funnel_bits(lo, hi, 64 - R));
+}
+MHX_HD uint64_t xorshift33(uint64_t k)
+{ // k ^= k >> 33: only the low word changes
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    return make64(lo ^ (hi >> 1), hi);
+}
+MHX_HD uint64_t times5_plus(uint64_t h, uint32_t c)
+{
+    const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+    const uint64_t t = (uint64_t)lo * 5u + c;
+    return make64((uint32_t)t, ((hi << 2) + hi) + (uint32_t)(t >> 32));
+}
 MHX_HD uint64_t fmix64(uint64_t k)
 {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return k;
+    k = xorshift33(k);
+    k = opaque64(k * 0xff51afd7ed558ccdull);
+    k = xorshift33(k);
+    k = opaque64(k * 0xc4ceb9fe1a85ec53ull);
+    return xorshift33(k);
 }
 // w: the K bytes as little-endian dwords, bytes beyond K zero
 template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
@@ -242,20 +304,20 @@ template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
     uint64_t h1 = 42, h2 = 42;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
-        uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
-        uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = rotl64(h1, 27); h1 += h2; h1 = ((h1 << 2) + h1) + 0x52dce729;
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = rotl64(h2, 31); h2 += h1; h2 = ((h2 << 2) + h2) + 0x38495ab5;
+        uint64_t k1 = make64(w[4 * b], w[4 * b + 1]);
+        uint64_t k2 = make64(w[4 * b + 2], w[4 * b + 3]);
+        k1 = rotl64<31>(opaque64(k1 * c1)); k1 *= c2; h1 ^= k1;
+        h1 = rotl64<27>(h1); h1 += h2; h1 = times5_plus(h1, 0x52dce729u);
+        k2 = rotl64<33>(opaque64(k2 * c2)); k2 *= c1; h2 ^= k2;
+        h2 = rotl64<31>(h2); h2 += h1; h2 = times5_plus(h2, 0x38495ab5u);
     }
     if (TAIL > 8) {
-        uint64_t k2 = (uint64_t)w[(4 * NBLK + 2) & 7] | ((uint64_t)w[(4 * NBLK + 3) & 7] << 32);
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        uint64_t k2 = make64(w[(4 * NBLK + 2) & 7], w[(4 * NBLK + 3) & 7]);
+        k2 = rotl64<33>(opaque64(k2 * c2)); k2 *= c1; h2 ^= k2;
     }
     if (TAIL > 0) {
-        uint64_t k1 = (uint64_t)w[(4 * NBLK) & 7] | ((uint64_t)w[(4 * NBLK + 1) & 7] << 32);
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        uint64_t k1 = make64(w[(4 * NBLK) & 7], w[(4 * NBLK + 1) & 7]);
+        k1 = rotl64<31>(opaque64(k1 * c1)); k1 *= c2; h1 ^= k1;
     }
     h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
     h1 += h2; h2 += h1;
@@ -336,7 +398,7 @@ MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_
             g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format, &lc);
             line += (uint32_t)__builtin_popcount(st.nl[w]);
         }
-        sm.good[tid * kWordsPerThread + w] = g;
+        tile_good(sm)[tid * kWordsPerThread + w] = g;
     }
     if (tid == 0) {
         uint32_t hl = line_base + tile_total;
@@ -348,10 +410,10 @@ MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_
                 g &= seqline_mask(st.hnl[w], hl, nullptr, 0, 0, ignore);
                 hl += (uint32_t)__builtin_popcount(st.hnl[w]);
             }
-            sm.good[kTileBytes / 32 + w] = g;
+            tile_good(sm)[kTileBytes / 32 + w] = g;
         }
-        sm.good[kTileBytes / 32 + 2] = 0;
-        sm.good[kTileBytes / 32 + 3] = 0;
+        tile_good(sm)[kTileBytes / 32 + 2] = 0;
+        tile_good(sm)[kTileBytes / 32 + 3] = 0;
     }
     return lc.count;
 }
@@ -362,7 +424,7 @@ template <int K> MHX_HD uint32_t phase_runs(TileSmem &sm, int tid, uint32_t &ite
     constexpr int NWD = kWordsPerThread;
     uint32_t w[NWD + 1], v[NWD];
 #pragma unroll
-    for (int i = 0; i < NWD + 1; ++i) w[i] = sm.good[tid * NWD + i];
+    for (int i = 0; i < NWD + 1; ++i) w[i] = tile_good(sm)[tid * NWD + i];
     run_starts<K, NWD>(w, v);
     uint32_t items = 0, kmers = 0;
 #pragma unroll
@@ -393,8 +455,15 @@ MHX_HD void phase_compact(TileSmem &sm, int tid, uint32_t excl)
 // bit 1 tells the two pairs apart (A,T: 0; C,G: 1).
 MHX_HD uint32_t complement4(uint32_t u)
 {
+#ifdef MHX_PERM_COMP
+    // bits 1..2 of a base index 'A','C','T','G' (0,1,2,3): the complement comes out of a 4-byte table in one
+    // v_perm_b32.  Bytes that are not A/C/G/T come out as one of the four letters as well; they only ever lie
+    // in windows whose valid bit is off.
+    return perm_lut(kLutComp, base_index(u));
+#else
     const uint32_t m = (u >> 1) & 0x01010101u;
     return u ^ 0x15151515u ^ (m | (m << 4));
+#endif
 }
 
 // 64 bits starting at byte offset `off` (compile-time) of the dword array a
@@ -447,7 +516,7 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
         const uint64_t top_f = load64<ND * 4 - 8 - J>(Wr);
         const uint64_t top_r = load64<J + K - 8>(Cc);
         bool rc = top_r < top_f;
-        if (K > 8 && top_r == top_f) { // cold: exact comparison
+        if (MHX_UNLIKELY(K > 8 && top_r == top_f)) { // cold: exact comparison
             // the copies go through an opaque barrier so that the compiler cannot hoist the
             // word extraction of this 4^-8 case in front of the branch (it did: ~19 wasted
             // instructions per window on the hot path)
@@ -459,6 +528,22 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
             extract_words<K, OR>(Rc, wr);
             rc = rc_is_smaller_full<NW>(wf, wr);
         }
+#ifdef MHX_XSEL
+        // extract both strands with compile-time shifts, then select the words: the eight windows of a group
+        // read the same byte offsets of U and R again and again (window J needs U at J, J+4, ..), so the
+        // extractions are common subexpressions across windows and only the NW selects are per window
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < NW) {
+                const uint32_t f = OF % 4 ? funnel(U[OF / 4 + i + 1], U[OF / 4 + i], OF % 4) : U[OF / 4 + i];
+                const uint32_t r = OR % 4 ? funnel(R[OR / 4 + i + 1], R[OR / 4 + i], OR % 4) : R[OR / 4 + i];
+                w[i] = rc ? r : f;
+            } else {
+                w[i] = 0u;
+            }
+        }
+        if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+#else
         // select the source dwords first, extract once
         uint32_t S[NW + 1];
 #pragma unroll
@@ -468,6 +553,7 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
         for (int i = 0; i < 8; ++i)
             w[i] = i < NW ? funnel_bits(S[i + 1], S[i], sh) : 0u;
         if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
+#endif
     } else {
         uint32_t wf[8], wr[8];
         extract_words<K, OF>(U, wf);
@@ -476,6 +562,41 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = rc ? wr[i] : wf[i];
     }
+    return murmur3_h1<K>(w);
+}
+
+// The same work split for the two-pass form of a group (K >= 8): first the strand of every window, then the hashes.
+// memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most significant first, are 8
+// little-endian bytes of Wr resp. Cc, so one 64-bit compare decides all but 4^-8 of the windows (`tie`).
+template <int K, int J, int ND>
+MHX_HD bool strand_fast(const uint32_t (&Wr)[ND + 1], const uint32_t (&Cc)[ND + 1], bool &tie)
+{
+    const uint64_t top_f = load64<ND * 4 - 8 - J>(Wr);
+    const uint64_t top_r = load64<J + K - 8>(Cc);
+    tie = K > 8 && top_r == top_f;
+    return top_r < top_f;
+}
+// exact strand comparison of one window (cold: only after a tie of the first 8 bases)
+template <int K, int J, int ND> MHX_HD bool strand_exact(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1])
+{
+    constexpr int NW = (K + 3) / 4;
+    uint32_t wf[8], wr[8];
+    extract_words<K, J>(U, wf);
+    extract_words<K, ND * 4 - K - J>(R, wr);
+    return rc_is_smaller_full<NW>(wf, wr);
+}
+// hash of the chosen strand: select the source dwords, extract the K bytes once, Murmur
+template <int K, int J, int ND> MHX_HD uint64_t strand_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1], bool rc)
+{
+    constexpr int NW = (K + 3) / 4;
+    constexpr int OF = J, OR = ND * 4 - K - J;
+    uint32_t S[NW + 1], w[8];
+#pragma unroll
+    for (int i = 0; i < NW + 1; ++i) S[i] = rc ? R[OR / 4 + i] : U[OF / 4 + i];
+    const uint32_t sh = rc ? 8u * (OR % 4) : 8u * (OF % 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = i < NW ? funnel_bits(S[i + 1], S[i], sh) : 0u;
+    if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
     return murmur3_h1<K>(w);
 }
 
@@ -504,11 +625,40 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
     U[ND] = R[ND] = Wr[ND] = Cc[ND] = 0;
     constexpr bool kHash32 = K <= 16; // mash keeps 32 bits when 4^k <= 2^32
     uint32_t ninserted = 0;
+#ifdef MHX_TWOPASS
+    if constexpr (K >= 8) {
+        // pass 1: the strand of all eight windows (lane masks); ties of the first 8 bases are settled for the
+        // whole group behind ONE rarely taken branch instead of one branch per window
+        bool rc[kGroup], tie[kGroup], any_tie = false;
+#define MHX_DECIDE(J) rc[J] = strand_fast<K, J, ND>(Wr, Cc, tie[J]); any_tie = any_tie || tie[J];
+        MHX_DECIDE(0) MHX_DECIDE(1) MHX_DECIDE(2) MHX_DECIDE(3) MHX_DECIDE(4) MHX_DECIDE(5) MHX_DECIDE(6) MHX_DECIDE(7)
+#undef MHX_DECIDE
+        if (MHX_UNLIKELY(any_tie)) {
+            uint32_t Uc[ND + 1], Rc[ND + 1]; // opaque copies: the cold extraction must not be hoisted in front of the branch
+#pragma unroll
+            for (int i = 0; i < ND + 1; ++i) { Uc[i] = opaque(U[i]); Rc[i] = opaque(R[i]); }
+#define MHX_EXACT(J) if (tie[J]) rc[J] = strand_exact<K, J, ND>(Uc, Rc);
+            MHX_EXACT(0) MHX_EXACT(1) MHX_EXACT(2) MHX_EXACT(3) MHX_EXACT(4) MHX_EXACT(5) MHX_EXACT(6) MHX_EXACT(7)
+#undef MHX_EXACT
+        }
+        // pass 2: hash of the chosen strand, admission
+#define MHX_HASH(J)                                                      \
+    {                                                                    \
+        uint64_t h = strand_hash<K, J, ND>(U, R, rc[J]);                 \
+        if (kHash32) h &= 0xFFFFFFFFull;                                 \
+        if (MHX_UNLIKELY(((vm >> J) & 1u) && h <= T)) { ins(h); ++ninserted; } \
+        sched_fence();                                                   \
+    }
+        MHX_HASH(0) MHX_HASH(1) MHX_HASH(2) MHX_HASH(3) MHX_HASH(4) MHX_HASH(5) MHX_HASH(6) MHX_HASH(7)
+#undef MHX_HASH
+        return ninserted;
+    }
+#endif
 #define MHX_WINDOW(J)                                                    \
     {                                                                    \
         uint64_t h = window_hash<K, J, ND>(U, R, Wr, Cc);                \
         if (kHash32) h &= 0xFFFFFFFFull;                                 \
-        if (((vm >> J) & 1u) && h <= T) { ins(h); ++ninserted; }         \
+        if (MHX_UNLIKELY(((vm >> J) & 1u) && h <= T)) { ins(h); ++ninserted; } \
     }
     MHX_WINDOW(0) MHX_WINDOW(1) MHX_WINDOW(2) MHX_WINDOW(3) MHX_WINDOW(4) MHX_WINDOW(5) MHX_WINDOW(6) MHX_WINDOW(7)
 #undef MHX_WINDOW
