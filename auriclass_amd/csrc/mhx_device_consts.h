@@ -29,7 +29,7 @@ constexpr uint64_t kFlagBadFastq = 2;    // a record violated the 4-line layout
 constexpr uint64_t kFlagSpinTimeout = 4; // look-back spin bound hit (should never happen)
 
 enum Stat : int {
-    kStatKmers = 0,   // valid windows hashed
+    kStatKmers = 0,   // windows hashed: k-mer starts with K bytes inside one sequence line / record (A/C/G/T or not)
     kStatInserts = 1, // occurrences admitted (hash <= threshold)
     kStatLines = 2,   // newline count of the FASTQ stream
     kStatFlags = 3,

@@ -353,6 +353,7 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
                 if (got == 0 && ferror(plain)) got = -1;
             }
             if (got < 0) {
+                if (crc_thread) crc_thread->drain(); // the follower may still be reading pieces of this chunk's buffer
                 st->error = std::string("ERROR: reading ") + path + " failed";
                 st->own_inflate_failed = own; // the caller repeats the run with zlib before giving up
                 close_all();

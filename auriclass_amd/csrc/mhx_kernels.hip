@@ -151,13 +151,17 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t value, uint32_t *wa
 
 // ---------------------------------------------------------------------------------------
 #ifndef MHX_MIN_WAVES
-#define MHX_MIN_WAVES 1
+#define MHX_MIN_WAVES 7   // 72 VGPRs: seven waves per SIMD, matching the seven workgroups per CU the LDS footprint admits
 #endif
 template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) void sketch_tile_kernel(const HashArgs a)
 {
     __shared__ TileSmem sm;
     constexpr bool FASTQ = (FMT == 1);
     const int tid = threadIdx.x;
+    // the parsing phases are latency-bound (loads, barriers, look-back): at high priority their few instructions do
+    // not queue behind the hash loops of the other resident workgroups, so a wave reaches its own hash loop sooner
+    // and more waves per SIMD are in VALU-dense code at any time (-2 % kernel time)
+    __builtin_amdgcn_s_setprio(3);
 
     // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
     uint32_t tile;
@@ -192,7 +196,8 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     MHX_STAMP(); // 0: stage (global loads -> LDS)
 
     ThreadState st;
-    phase_classify<FASTQ>(sm, tid, st, tile_off, a.begin, a.end);
+    const bool interior = tile_off >= a.begin && tile_off + kTileBytes + kHaloBytes <= a.end; // nothing to mask out
+    phase_classify(sm, tid, st, tile_off, a.begin, a.end, interior);
 
     MHX_STAMP(); // 1: classify
     uint32_t line_base = 0, excl = 0, tile_total = 0;
@@ -224,11 +229,13 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     phase_compact(sm, tid, items_before);
     __syncthreads();
     MHX_STAMP(); // 4: valid starts + work list
+    __builtin_amdgcn_s_setprio(0);
 
     const uint64_t T = *a.thresh;
+    const uint32_t limit = admission_limit(T);
     DeviceInserter ins{reinterpret_cast<unsigned long long *>(a.keys), a.cnts, a.slot_mask, stats};
     uint32_t ninsert = 0;
-    for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K>(sm, sm.list[it], T, a.hash32 != 0, ins);
+    for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K>(sm, sm.list[it], T, limit, ins);
     if (ninsert) atomicAdd(&sm.misc[4], ninsert);
     __syncthreads();
     MHX_STAMP(); // 5: work loop

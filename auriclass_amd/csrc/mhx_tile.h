@@ -6,13 +6,19 @@
 // What one tile does (replaces mash's kseq_read + addMinHashes + getHash hot loop,
 // Mash 2.x Sketch.cpp; reached from /root/reference/auriclass/classes.py:576-596,696-713):
 //   stage     16 KiB (+64 B halo) of the byte stream into LDS, 16 B per lane, coalesced
-//   classify  per byte: newline?  A/C/G/T (either case)?        -> bit masks (SIMD-in-register)
+//   classify  per byte: newline?                                 -> bit mask (SIMD-in-register)
 //   phase     FASTQ: newline prefix -> line number mod 4 == 1 marks sequence lines
-//   runs      valid k-mer starts = runs of >= K good bytes       -> 1 bit per position
-//   compact   groups of 8 start positions with any valid start   -> LDS work list
+//   runs      candidate k-mer starts = K bytes inside one line   -> 1 bit per position
+//   compact   groups of 8 start positions with any candidate     -> LDS work list
 //   work      each lane takes a group: 8 windows share one 28..39 byte register chunk;
-//             canonical strand by big-endian compare, MurmurHash3_x64_128(seed 42),
-//             admission test against the global threshold, insert into the device table
+//             canonical strand by big-endian compare, MurmurHash3_x64_128(seed 42) up to its
+//             last two steps, a 32-bit necessary test against the global threshold; the few
+//             windows that pass finish the hash, are checked base by base (A/C/G/T, either
+//             case -- mash skips every window holding anything else) and go into the table.
+// The base check is deferred on purpose: one window in 10^4..10^6 is ever a candidate, so
+// testing every byte of the stream for A/C/G/T up front cost more than hashing the rare
+// window that holds an N (its hash is garbage, it passes the threshold as rarely as any
+// other, and the exact check then drops it).
 #pragma once
 #include <stdint.h>
 
@@ -26,50 +32,34 @@ struct uint4 { uint32_t x, y, z, w; };
 
 #include "mhx_device_consts.h"
 
-#ifdef MHX_EXPECT
+// rare branches are laid out of line: the hot path falls through instead of jumping over the cold block
 #define MHX_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#else
-#define MHX_UNLIKELY(x) (x)
-#endif
 
 namespace mhx {
 
 constexpr int kMapWords = (kTileBytes + kHaloBytes) / 32 + 2; // words of a 1-bit-per-byte map of tile + halo (+2 look-ahead)
 struct TileSmem {
     uint4 bytes[(kTileBytes + kHaloBytes) / 16];      // staged stream bytes
-#ifndef MHX_LDS_ALIAS
-    uint32_t good[kMapWords];                          // 1 bit per byte: usable base
-#endif
-    uint32_t valid[kGroupsPerTile / 4];                // byte g = valid-start mask of group g
-#ifdef MHX_LDS_ALIAS
+    uint32_t valid[kGroupsPerTile / 4];                // byte g = candidate-start mask of group g
     // One area, three tenants with disjoint lifetimes: the newline map (classify -> good-map phase) and the
-    // good-base map (good-map phase -> valid starts) side by side, then the work list (compaction -> hash loop).
+    // good map (good-map phase -> candidate starts) side by side, then the work list (compaction -> hash loop).
+    // 22.7 KB of LDS per workgroup in all: seven workgroups per CU.
     union {
-        uint16_t list[kGroupsPerTile];
+        uint16_t list[kGroupsPerTile];                 // compacted work list (group ids)
         uint32_t maps[2 * kMapWords];
     };
-#else
-    uint16_t list[kGroupsPerTile];                     // compacted work list (group ids)
-#endif
     uint32_t cnt[16];                                  // wave partials of the two workgroup scans
     uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
 };
 
-// The newline bit map of the tile lives in the (not yet used) work-list area between the classify
-// and the good-map phases: 1 bit per byte, kTileBytes/32 + 2 words.
-#ifdef MHX_LDS_ALIAS
-MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return sm.maps; }
-MHX_HD uint32_t *tile_good(TileSmem &sm) { return sm.maps + kMapWords; }
-#else
-static_assert(sizeof(uint16_t) * kGroupsPerTile >= sizeof(uint32_t) * (kTileBytes / 32 + 2), "nl map must fit the list area");
-MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return reinterpret_cast<uint32_t *>(sm.list); }
-MHX_HD uint32_t *tile_good(TileSmem &sm) { return sm.good; }
-#endif
+MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return sm.maps; }             // 1 bit per byte: newline
+MHX_HD uint32_t *tile_good(TileSmem &sm) { return sm.maps + kMapWords; } // 1 bit per byte: may be covered by a k-mer
 
 // per-thread state carried between phases (registers on the GPU)
 struct ThreadState {
-    uint32_t nl[kWordsPerThread], acgt[kWordsPerThread]; // masks of this thread's 32-byte words
-    uint32_t hnl[2], hacgt[2];     // thread 0 only: the two halo words
+    uint32_t nl[kWordsPerThread];  // newline mask of this thread's 32-byte words (bytes outside the span cleared)
+    uint32_t in[kWordsPerThread];  // bytes of those words that lie inside the span
+    uint32_t hnl[2], hin[2];       // thread 0 only: the two halo words
     uint32_t nlcount;
 };
 
@@ -118,14 +108,6 @@ MHX_HD uint32_t opaque(uint32_t v)
 #endif
     return v;
 }
-// nothing is scheduled across this point (keeps the eight windows of a group from being interleaved, which
-// costs more registers than the overlap is worth)
-MHX_HD void sched_fence()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
 { // bit_shift in 0..31
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,20 +117,19 @@ MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
 #endif
 }
 
-// newline and A/C/G/T masks of one 32-byte word (8 dwords at p)
-template <bool WANT_NL> MHX_HD void classify_word(const uint32_t *p, uint32_t &nl, uint32_t &acgt)
+// newline mask of one 32-byte word (8 dwords at p)
+MHX_HD uint32_t newline_mask(const uint32_t *p)
 {
-    uint32_t n = 0, a = 0;
+    uint32_t n = 0;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        const uint32_t v = p[d];
-        if (WANT_NL) n |= flags_to_nibble(zero_byte_flags(v ^ 0x0A0A0A0Au)) << (4 * d);
-        const uint32_t u = v & 0xDFDFDFDFu;
-        const uint32_t asc = perm_lut(kLutBase, base_index(u));
-        a |= flags_to_nibble(zero_byte_flags(asc ^ u)) << (4 * d);
-    }
-    nl = n;
-    acgt = a;
+    for (int d = 0; d < 8; ++d) n |= flags_to_nibble(zero_byte_flags(p[d] ^ 0x0A0A0A0Au)) << (4 * d);
+    return n;
+}
+// A/C/G/T (either case) mask of the four bytes of a dword, as flags 0x80 per byte
+MHX_HD uint32_t acgt_flags(uint32_t v)
+{
+    const uint32_t u = v & 0xDFDFDFDFu;
+    return zero_byte_flags(perm_lut(kLutBase, base_index(u)) ^ u);
 }
 
 // bits of a 32-byte word starting at absolute offset A that lie inside [begin, end)
@@ -288,16 +269,32 @@ MHX_HD uint64_t times5_plus(uint64_t h, uint32_t c)
     const uint64_t t = (uint64_t)lo * 5u + c;
     return make64((uint32_t)t, ((hi << 2) + hi) + (uint32_t)(t >> 32));
 }
-MHX_HD uint64_t fmix64(uint64_t k)
+// fmix64 without its last step (k ^= k >> 33 changes only the low word, see Murmur3Tail::finish)
+MHX_HD uint64_t fmix64_head(uint64_t k)
 {
     k = xorshift33(k);
     k = opaque64(k * 0xff51afd7ed558ccdull);
     k = xorshift33(k);
-    k = opaque64(k * 0xc4ceb9fe1a85ec53ull);
-    return xorshift33(k);
+    return opaque64(k * 0xc4ceb9fe1a85ec53ull);
+}
+// The hash up to its last two steps: h = xorshift33(a) + xorshift33(b).  The high word of h is
+// hi(a) + hi(b) or that plus one, so `h <= T` implies hi(a) + hi(b) + 1 <= hi(T) + 1 (mod 2^32, see
+// admission_limit): one 32-bit add and one compare reject all but ~T / 2^64 of the windows without the
+// two shift-xors and the 64-bit add.
+struct Murmur3Tail {
+    uint64_t a, b;
+    MHX_HD uint64_t finish() const { return xorshift33(a) + xorshift33(b); }
+    MHX_HD uint32_t low32() const { return (uint32_t)xorshift33(a) + (uint32_t)xorshift33(b); } // 32-bit hashes (k <= 16)
+    MHX_HD uint32_t high_bound() const { return (uint32_t)(a >> 32) + (uint32_t)(b >> 32) + 1u; }
+};
+// largest value of Murmur3Tail::high_bound() a hash <= T can have
+MHX_HD uint32_t admission_limit(uint64_t T)
+{
+    const uint32_t th = (uint32_t)(T >> 32);
+    return th == 0xFFFFFFFFu ? th : th + 1u;
 }
 // w: the K bytes as little-endian dwords, bytes beyond K zero
-template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
+template <int K> MHX_HD Murmur3Tail murmur3_core(const uint32_t (&w)[8])
 {
     constexpr uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
     constexpr int NBLK = K / 16, TAIL = K & 15;
@@ -321,10 +318,9 @@ template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8])
     }
     h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
     h1 += h2; h2 += h1;
-    h1 = fmix64(h1); h2 = fmix64(h2);
-    h1 += h2;
-    return h1;
+    return Murmur3Tail{fmix64_head(h1), fmix64_head(h2)};
 }
+template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8]) { return murmur3_core<K>(w).finish(); }
 
 // ---- phases -------------------------------------------------------------------------
 
@@ -350,39 +346,34 @@ MHX_HD void phase_stage(TileSmem &sm, int tid, const uint8_t *base, uint64_t til
     }
 }
 
-// P2a: masks of this thread's 128 bytes (and, for thread 0, of the halo)
-template <bool FASTQ>
-MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile_off, uint64_t begin, uint64_t end)
+// P2a: newline mask of this thread's 128 bytes (and, for thread 0, of the halo).  `interior`: the tile and its
+// halo lie inside the span, so no byte has to be masked out (wave-uniform: all tiles but the first and the last)
+MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile_off, uint64_t begin, uint64_t end, bool interior)
 {
     const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + tid * (kBytesPerThread / 4);
     uint32_t total = 0;
 #pragma unroll
     for (int w = 0; w < kWordsPerThread; ++w) {
-        uint32_t nl, ac;
-        classify_word<FASTQ>(p + 8 * w, nl, ac);
-        const uint32_t in = inrange_mask(tile_off + (uint64_t)tid * kBytesPerThread + 32u * w, begin, end);
-        st.nl[w] = nl & in;
-        st.acgt[w] = ac & in;
+        st.in[w] = interior ? 0xFFFFFFFFu : inrange_mask(tile_off + (uint64_t)tid * kBytesPerThread + 32u * w, begin, end);
+        st.nl[w] = newline_mask(p + 8 * w) & st.in[w];
         total += (uint32_t)__builtin_popcount(st.nl[w]);
-        if (FASTQ) tile_nlmap(sm)[tid * kWordsPerThread + w] = st.nl[w];
+        tile_nlmap(sm)[tid * kWordsPerThread + w] = st.nl[w];
     }
     st.nlcount = total;
     if (tid == 0) {
         const uint32_t *h = reinterpret_cast<const uint32_t *>(sm.bytes) + kTileBytes / 4;
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            uint32_t nl, ac;
-            classify_word<FASTQ>(h + 8 * w, nl, ac);
-            const uint32_t in = inrange_mask(tile_off + kTileBytes + 32u * w, begin, end);
-            st.hnl[w] = nl & in;
-            st.hacgt[w] = ac & in;
-            if (FASTQ) tile_nlmap(sm)[kTileBytes / 32 + w] = st.hnl[w];
+            st.hin[w] = interior ? 0xFFFFFFFFu : inrange_mask(tile_off + kTileBytes + 32u * w, begin, end);
+            st.hnl[w] = newline_mask(h + 8 * w) & st.hin[w];
+            tile_nlmap(sm)[kTileBytes / 32 + w] = st.hnl[w];
         }
     }
 }
 
 
-// P2c: good-base bits -> sm.good
+// P2c: bytes a k-mer may cover -> good map: FASTQ: the bytes of sequence lines; sequence stream: everything but the
+// record separators.  (Whether they are A/C/G/T is checked for the few windows that pass the threshold.)
 // returns the number of records of this thread's bytes whose sequence line holds >= k bytes
 template <bool FASTQ>
 MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_t line_base, uint32_t excl,
@@ -393,10 +384,12 @@ MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_
     uint32_t line = line_base + excl;
 #pragma unroll
     for (int w = 0; w < kWordsPerThread; ++w) {
-        uint32_t g = st.acgt[w];
+        uint32_t g;
         if (FASTQ) {
-            g &= seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format, &lc);
+            g = st.in[w] & seqline_mask(st.nl[w], line, tb, (uint32_t)tid * kBytesPerThread + 32u * w, check_limit, bad_format, &lc);
             line += (uint32_t)__builtin_popcount(st.nl[w]);
+        } else {
+            g = st.in[w] & ~st.nl[w];
         }
         tile_good(sm)[tid * kWordsPerThread + w] = g;
     }
@@ -404,11 +397,13 @@ MHX_HD uint32_t phase_good(TileSmem &sm, int tid, const ThreadState &st, uint32_
         uint32_t hl = line_base + tile_total;
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            uint32_t g = st.hacgt[w];
+            uint32_t g;
             if (FASTQ) {
                 bool ignore = false;
-                g &= seqline_mask(st.hnl[w], hl, nullptr, 0, 0, ignore);
+                g = st.hin[w] & seqline_mask(st.hnl[w], hl, nullptr, 0, 0, ignore);
                 hl += (uint32_t)__builtin_popcount(st.hnl[w]);
+            } else {
+                g = st.hin[w] & ~st.hnl[w];
             }
             tile_good(sm)[kTileBytes / 32 + w] = g;
         }
@@ -451,20 +446,10 @@ MHX_HD void phase_compact(TileSmem &sm, int tid, uint32_t excl)
     if (tid == kBlock - 1) sm.misc[1] = pos;
 }
 
-// ASCII complement of four folded bases at once: A<->T differ by 0x15, C<->G by 0x04, and
-// bit 1 tells the two pairs apart (A,T: 0; C,G: 1).
-MHX_HD uint32_t complement4(uint32_t u)
-{
-#ifdef MHX_PERM_COMP
-    // bits 1..2 of a base index 'A','C','T','G' (0,1,2,3): the complement comes out of a 4-byte table in one
-    // v_perm_b32.  Bytes that are not A/C/G/T come out as one of the four letters as well; they only ever lie
-    // in windows whose valid bit is off.
-    return perm_lut(kLutComp, base_index(u));
-#else
-    const uint32_t m = (u >> 1) & 0x01010101u;
-    return u ^ 0x15151515u ^ (m | (m << 4));
-#endif
-}
+// ASCII complement of four folded bases at once: bits 1..2 of a base tell 'A','C','T','G' apart (0,1,2,3) and the
+// complement comes out of a 4-byte table in one v_perm_b32.  Bytes that are not A/C/G/T come out as one of
+// the four letters as well; a window that holds one never reaches the table (window_is_acgt).
+MHX_HD uint32_t complement4(uint32_t u) { return perm_lut(kLutComp, base_index(u)); }
 
 // 64 bits starting at byte offset `off` (compile-time) of the dword array a
 template <int OFF, int N> MHX_HD uint64_t load64(const uint32_t (&a)[N])
@@ -498,17 +483,16 @@ template <int K, int OFF, int N> MHX_HD void extract_words(const uint32_t (&src)
     if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
 }
 
-// One window: canonical strand -> hash.  U = folded forward chunk, R = its reverse
-// complement, Wr = the forward chunk byte-reversed, Cc = the forward chunk complemented
-// (the last two only feed the strand decision).
+// One window: the K bytes of its canonical strand as little-endian words.  U = folded forward chunk, R = its
+// reverse complement, Wr = the forward chunk byte-reversed, Cc = the forward chunk complemented (the last two
+// only feed the strand decision).
 template <int K, int J, int ND>
-MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1], const uint32_t (&Wr)[ND + 1],
-                            const uint32_t (&Cc)[ND + 1])
+MHX_HD void canonical_words(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1], const uint32_t (&Wr)[ND + 1],
+                            const uint32_t (&Cc)[ND + 1], uint32_t (&w)[8])
 {
     constexpr int NW = (K + 3) / 4;
     constexpr int OF = J;               // forward window starts at U byte OF
     constexpr int OR = ND * 4 - K - J;  // its reverse complement starts at R byte OR
-    uint32_t w[8];
     if constexpr (K >= 8) {
         // memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most
         // significant first, are 8 little-endian bytes of Wr resp. Cc.  Equal first 8 bases
@@ -528,22 +512,6 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
             extract_words<K, OR>(Rc, wr);
             rc = rc_is_smaller_full<NW>(wf, wr);
         }
-#ifdef MHX_XSEL
-        // extract both strands with compile-time shifts, then select the words: the eight windows of a group
-        // read the same byte offsets of U and R again and again (window J needs U at J, J+4, ..), so the
-        // extractions are common subexpressions across windows and only the NW selects are per window
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < NW) {
-                const uint32_t f = OF % 4 ? funnel(U[OF / 4 + i + 1], U[OF / 4 + i], OF % 4) : U[OF / 4 + i];
-                const uint32_t r = OR % 4 ? funnel(R[OR / 4 + i + 1], R[OR / 4 + i], OR % 4) : R[OR / 4 + i];
-                w[i] = rc ? r : f;
-            } else {
-                w[i] = 0u;
-            }
-        }
-        if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
-#else
         // select the source dwords first, extract once
         uint32_t S[NW + 1];
 #pragma unroll
@@ -553,7 +521,6 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
         for (int i = 0; i < 8; ++i)
             w[i] = i < NW ? funnel_bits(S[i + 1], S[i], sh) : 0u;
         if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
-#endif
     } else {
         uint32_t wf[8], wr[8];
         extract_words<K, OF>(U, wf);
@@ -562,53 +529,30 @@ MHX_HD uint64_t window_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = rc ? wr[i] : wf[i];
     }
-    return murmur3_h1<K>(w);
-}
-
-// The same work split for the two-pass form of a group (K >= 8): first the strand of every window, then the hashes.
-// memcmp(fwd, rc) compares big-endian; the first 8 bases of either strand, most significant first, are 8
-// little-endian bytes of Wr resp. Cc, so one 64-bit compare decides all but 4^-8 of the windows (`tie`).
-template <int K, int J, int ND>
-MHX_HD bool strand_fast(const uint32_t (&Wr)[ND + 1], const uint32_t (&Cc)[ND + 1], bool &tie)
-{
-    const uint64_t top_f = load64<ND * 4 - 8 - J>(Wr);
-    const uint64_t top_r = load64<J + K - 8>(Cc);
-    tie = K > 8 && top_r == top_f;
-    return top_r < top_f;
-}
-// exact strand comparison of one window (cold: only after a tie of the first 8 bases)
-template <int K, int J, int ND> MHX_HD bool strand_exact(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1])
-{
-    constexpr int NW = (K + 3) / 4;
-    uint32_t wf[8], wr[8];
-    extract_words<K, J>(U, wf);
-    extract_words<K, ND * 4 - K - J>(R, wr);
-    return rc_is_smaller_full<NW>(wf, wr);
-}
-// hash of the chosen strand: select the source dwords, extract the K bytes once, Murmur
-template <int K, int J, int ND> MHX_HD uint64_t strand_hash(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND + 1], bool rc)
-{
-    constexpr int NW = (K + 3) / 4;
-    constexpr int OF = J, OR = ND * 4 - K - J;
-    uint32_t S[NW + 1], w[8];
-#pragma unroll
-    for (int i = 0; i < NW + 1; ++i) S[i] = rc ? R[OR / 4 + i] : U[OF / 4 + i];
-    const uint32_t sh = rc ? 8u * (OR % 4) : 8u * (OF % 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = i < NW ? funnel_bits(S[i + 1], S[i], sh) : 0u;
-    if (K % 4) w[NW - 1] &= (1u << (8 * (K % 4))) - 1u;
-    return murmur3_h1<K>(w);
 }
 
 // P5: one work item = 8 consecutive window starts sharing one register chunk.
-// ins(h) is called for every valid window whose hash is <= T.
 template <int K> struct GroupGeom {
     static constexpr int NB = kGroup + K - 1; // bytes touched
     static constexpr int ND = (NB + 3) / 4;   // dwords loaded
 };
 
+// Cold path, reached by one window in ~2^64 / T: are bytes J .. J+K-1 of the chunk all A/C/G/T (either case)?
+// mash skips every window that holds anything else (Sketch.cpp addMinHashes).
+// (chunk: the raw or the case-folded bytes, the test folds anyway)
+template <int K, int J, int ND> MHX_HD bool window_is_acgt(const uint32_t (&chunk)[ND + 1])
+{
+    uint64_t m = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) m |= (uint64_t)flags_to_nibble(acgt_flags(chunk[d])) << (4 * d);
+    constexpr uint64_t want = (K >= 64 ? ~0ull : ((1ull << K) - 1ull)) << J;
+    return (m & want) == want;
+}
+
+// ins(h) is called for every window that is a candidate start (bit of vm), consists of A/C/G/T only and whose hash
+// is <= T.  `limit` = admission_limit(T).
 template <int K, class Ins>
-MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint32_t vm, uint64_t T, Ins &ins)
+MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint32_t vm, uint64_t T, uint32_t limit, Ins &ins)
 {
     constexpr int ND = GroupGeom<K>::ND;
     uint32_t U[ND + 1], R[ND + 1], Wr[ND + 1], Cc[ND + 1];
@@ -625,40 +569,17 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
     U[ND] = R[ND] = Wr[ND] = Cc[ND] = 0;
     constexpr bool kHash32 = K <= 16; // mash keeps 32 bits when 4^k <= 2^32
     uint32_t ninserted = 0;
-#ifdef MHX_TWOPASS
-    if constexpr (K >= 8) {
-        // pass 1: the strand of all eight windows (lane masks); ties of the first 8 bases are settled for the
-        // whole group behind ONE rarely taken branch instead of one branch per window
-        bool rc[kGroup], tie[kGroup], any_tie = false;
-#define MHX_DECIDE(J) rc[J] = strand_fast<K, J, ND>(Wr, Cc, tie[J]); any_tie = any_tie || tie[J];
-        MHX_DECIDE(0) MHX_DECIDE(1) MHX_DECIDE(2) MHX_DECIDE(3) MHX_DECIDE(4) MHX_DECIDE(5) MHX_DECIDE(6) MHX_DECIDE(7)
-#undef MHX_DECIDE
-        if (MHX_UNLIKELY(any_tie)) {
-            uint32_t Uc[ND + 1], Rc[ND + 1]; // opaque copies: the cold extraction must not be hoisted in front of the branch
-#pragma unroll
-            for (int i = 0; i < ND + 1; ++i) { Uc[i] = opaque(U[i]); Rc[i] = opaque(R[i]); }
-#define MHX_EXACT(J) if (tie[J]) rc[J] = strand_exact<K, J, ND>(Uc, Rc);
-            MHX_EXACT(0) MHX_EXACT(1) MHX_EXACT(2) MHX_EXACT(3) MHX_EXACT(4) MHX_EXACT(5) MHX_EXACT(6) MHX_EXACT(7)
-#undef MHX_EXACT
-        }
-        // pass 2: hash of the chosen strand, admission
-#define MHX_HASH(J)                                                      \
-    {                                                                    \
-        uint64_t h = strand_hash<K, J, ND>(U, R, rc[J]);                 \
-        if (kHash32) h &= 0xFFFFFFFFull;                                 \
-        if (MHX_UNLIKELY(((vm >> J) & 1u) && h <= T)) { ins(h); ++ninserted; } \
-        sched_fence();                                                   \
-    }
-        MHX_HASH(0) MHX_HASH(1) MHX_HASH(2) MHX_HASH(3) MHX_HASH(4) MHX_HASH(5) MHX_HASH(6) MHX_HASH(7)
-#undef MHX_HASH
-        return ninserted;
-    }
-#endif
-#define MHX_WINDOW(J)                                                    \
-    {                                                                    \
-        uint64_t h = window_hash<K, J, ND>(U, R, Wr, Cc);                \
-        if (kHash32) h &= 0xFFFFFFFFull;                                 \
-        if (MHX_UNLIKELY(((vm >> J) & 1u) && h <= T)) { ins(h); ++ninserted; } \
+#define MHX_WINDOW(J)                                                                         \
+    {                                                                                         \
+        uint32_t w[8];                                                                        \
+        canonical_words<K, J, ND>(U, R, Wr, Cc, w);                                           \
+        const Murmur3Tail tail = murmur3_core<K>(w);                                          \
+        /* necessary condition of h <= T, one add + one compare (32-bit hashes: the exact low word) */ \
+        const bool candidate = kHash32 ? tail.low32() <= (uint32_t)T : tail.high_bound() <= limit; \
+        if (MHX_UNLIKELY(candidate)) {                                                        \
+            const uint64_t h = kHash32 ? (uint64_t)tail.low32() : tail.finish();              \
+            if (((vm >> J) & 1u) && h <= T && window_is_acgt<K, J, ND>(U)) { ins(h); ++ninserted; }   \
+        }                                                                                     \
     }
     MHX_WINDOW(0) MHX_WINDOW(1) MHX_WINDOW(2) MHX_WINDOW(3) MHX_WINDOW(4) MHX_WINDOW(5) MHX_WINDOW(6) MHX_WINDOW(7)
 #undef MHX_WINDOW
@@ -668,16 +589,15 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
 
 // work item g of a staged tile (LDS source)
 template <int K, class Ins>
-MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, bool hash32, Ins &ins)
+MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, uint32_t limit, Ins &ins)
 {
     constexpr int ND = GroupGeom<K>::ND;
-    (void)hash32;
     const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
     const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
     uint32_t src[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) src[d] = p[d];
-    return process_group_regs<K>(src, vm, T, ins);
+    return process_group_regs<K>(src, vm, T, limit, ins);
 }
 
 } // namespace mhx

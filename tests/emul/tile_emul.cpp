@@ -29,7 +29,8 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
     for (uint32_t tile = first_tile; tile < ntiles; ++tile) {
         const uint64_t tile_off = (uint64_t)tile * kTileBytes;
         for (int t = 0; t < kBlock; ++t) phase_stage(sm, t, base, tile_off, end);
-        for (int t = 0; t < kBlock; ++t) phase_classify<FASTQ>(sm, t, st[t], tile_off, begin, end);
+        const bool interior = tile_off >= begin && tile_off + kTileBytes + kHaloBytes <= end;
+        for (int t = 0; t < kBlock; ++t) phase_classify(sm, t, st[t], tile_off, begin, end, interior);
         uint32_t excl[kBlock] = {0}, tile_total = 0;
         if (FASTQ) { // the kernel's block_scan_excl
             for (int t = 0; t < kBlock; ++t) { excl[t] = tile_total; tile_total += st[t].nlcount; }
@@ -45,7 +46,7 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         for (int t = 0; t < kBlock; ++t) { uint32_t items = 0; stats[kStatKmers] += phase_runs<K>(sm, t, items); ex2[t] = run; run += items; }
         for (int t = 0; t < kBlock; ++t) phase_compact(sm, t, ex2[t]);
         const uint32_t nitems = sm.misc[1];
-        for (uint32_t it = 0; it < nitems; ++it) stats[kStatInserts] += process_group<K>(sm, sm.list[it], T, hash32, ins);
+        for (uint32_t it = 0; it < nitems; ++it) stats[kStatInserts] += process_group<K>(sm, sm.list[it], T, admission_limit(T), ins);
         stats[kStatLines] += tile_total;
     }
 }

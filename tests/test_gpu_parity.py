@@ -66,7 +66,9 @@ def test_seq_stream_equals_oracle(k, s, m):
     for r in reads:
         ref.add_seq(r)
     assert np.array_equal(got_h, ref.finish()[0])
-    assert stats["kmers"] == ref.kmers
+    # windows hashed: every start with k bytes inside one record (those holding a non-ACGT byte are dropped by the
+    # deferred base check before they reach the table)
+    assert stats["kmers"] == sum(max(0, len(r) - k + 1) for r in reads) >= ref.kmers
     assert stats["flags"] == 0
 
 

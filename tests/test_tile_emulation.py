@@ -88,7 +88,9 @@ def test_seq_stream(emul, k):
     data = b"\n".join(reads) + b"\n"
     got, stats = run_emul(emul, data, k, fmt=0)
     want = oracle_hashes(reads, k)
-    assert stats[0] == len(want)
+    # windows hashed = every start with k bytes inside one record; the ones holding a non-ACGT byte are dropped
+    # by the deferred base check, so the admitted hashes are exactly the oracle's
+    assert stats[0] == sum(max(0, len(r) - k + 1) for r in reads) >= len(want)
     assert np.array_equal(got, want)
 
 
@@ -102,7 +104,7 @@ def test_fastq4_stream(emul, k, lead):
     want = oracle_hashes(reads, k)
     assert int(stats[3]) == 0, "format flag raised on a valid FASTQ"
     assert int(stats[2]) == 4 * len(reads)
-    assert stats[0] == len(want)
+    assert stats[0] == sum(max(0, len(r) - k + 1) for r in reads) >= len(want)
     assert np.array_equal(got, want)
 
 
