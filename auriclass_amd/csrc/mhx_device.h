@@ -31,6 +31,7 @@ struct TableArgs {
     uint32_t *hist;      // kHistBins counters, zero between rounds
     uint64_t *acc;       // kAccReplicas x 8 words: accumulators of the tighten pass (occupied, solid), zero between rounds
     uint64_t *stats;
+    uint32_t *done;      // ticket of the tighten pass (its last workgroup computes the new threshold), zero between rounds
     uint32_t min_mult;
     uint32_t sketch_size;
     uint32_t sample;     // tighten pass looks at one 256-slot block in `sample` (1 = exact pass)
@@ -39,9 +40,11 @@ struct TableArgs {
 // launchers (mhx_kernels.hip)
 hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st);
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st);
+hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n, hipStream_t st);
 hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, hipStream_t st);
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
-                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev, hipStream_t st);
+                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st);
 bool hash_k_supported(int k);
 
 struct DistArgs {

@@ -120,7 +120,9 @@ struct mhx_sketcher {
     uint32_t *d_hist = nullptr;
     uint64_t *d_acc = nullptr;
     uint64_t *d_stats = nullptr;   // kStatReplicas x kStatCount
-    uint32_t *d_tickets = nullptr; // one per launch of a push
+    uint32_t *d_tickets = nullptr; // one per tile launch since the last reset (kTicketWords of them)
+    uint32_t tickets_used = 0;
+    uint32_t *d_done = nullptr;    // ticket of the tighten pass
     uint64_t *d_tile_state = nullptr;
     size_t tile_state_cap = 0;
     uint8_t *d_stage = nullptr;
@@ -129,10 +131,13 @@ struct mhx_sketcher {
     uint32_t *d_out_cnts = nullptr;
     uint32_t *d_out_n = nullptr;
     uint32_t out_cap = 0;
+    // finish(): one device block [n, T, flags, #(2^64-1) | hashes[fin_cap] | counts[fin_cap]] and its pinned host
+    // mirror, so the result comes back in ONE copy (five separate copies cost 20-60 us of idle gap each)
+    uint64_t *d_fin = nullptr, *h_fin = nullptr;
+    uint32_t fin_cap = 0;
+    bool table_dirty = true;   // tiles have been hashed since the last tighten pass
     // host
     uint64_t next_chunk_bytes = 0; // geometric schedule of the tightening phase
-    bool settled = false;          // threshold tight enough: remaining data goes in one launch
-    uint64_t settled_total = 0;    // input size that decision was made for
     uint64_t bytes_pushed = 0;
     uint64_t expected_bytes = 0;
     uint64_t admit_scale = 1;      // multiplies the initial admission budget (retries after MHX_E_CAPACITY)
@@ -149,17 +154,18 @@ struct mhx_sketcher {
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
+static constexpr uint32_t kTicketWords = 4096; // tile launches between two clears of the ticket words
 #ifndef MHX_CHUNK_GROWTH
 #define MHX_CHUNK_GROWTH 16
 #endif
-static constexpr uint64_t kChunkGrowth = MHX_CHUNK_GROWTH; // chunk size ratio between tighten rounds
+static constexpr uint64_t kChunkGrowth = MHX_CHUNK_GROWTH; // smallest chunk size ratio between tighten rounds
 static constexpr uint64_t kUncappedBytes = 1u << 20;       // m > 1: prefix of the input that is admitted whole
 
 static TableArgs table_args(mhx_sketcher *sk)
 {
     TableArgs t;
     t.keys = sk->d_keys; t.cnts = sk->d_cnts; t.nslots = sk->nslots; t.thresh = sk->d_thresh;
-    t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.min_mult = sk->m; t.sketch_size = sk->s;
+    t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.done = sk->d_done; t.min_mult = sk->m; t.sketch_size = sk->s;
     t.sample = 1;
     return t;
 }
@@ -168,8 +174,10 @@ static void free_sketcher(mhx_sketcher *sk)
 {
     if (!sk) return;
     hipFree(sk->d_keys); hipFree(sk->d_cnts); hipFree(sk->d_thresh); hipFree(sk->d_hist); hipFree(sk->d_acc);
-    hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
+    hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
     hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
+    hipFree(sk->d_fin);
+    if (sk->h_fin) hipHostFree(sk->h_fin);
     delete sk;
 }
 
@@ -186,28 +194,23 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     int rc = require_engine();
     if (rc) return rc;
     if (!sk) return fail(MHX_E_ARG, "null sketcher");
-    HIPCHK(hipMemsetAsync(sk->d_keys, 0xFF, sk->nslots * sizeof(uint64_t), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_cnts, 0, sk->nslots * sizeof(uint32_t), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_hist, 0, kHistBins * sizeof(uint32_t), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_acc, 0, kAccReplicas * 8 * sizeof(uint64_t), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_stats, 0, kStatReplicas * kStatCount * sizeof(uint64_t), g.stream));
     // Admission threshold: everything is admitted at first.  For m = 1 the first tighten pass already
     // finds s entries; for m > 1 push_device keeps the table safe until s solid hashes exist.
     sk->t_init = sk->hash_max;
+    // one launch: table vacated, histogram / accumulators / counters / tickets cleared, T = t_init
+    HIPCHK(launch_reset(table_args(sk), sk->t_init, sk->d_tickets, kTicketWords, sk->d_out_n, g.stream));
+    sk->tickets_used = 0;
+    sk->table_dirty = true;
     sk->last_T = sk->hash_max;
     sk->bounded = false;
     sk->established = false;
     sk->occupied = 0;
     sk->solid = 0;
-    // t_init lives in the sketcher and is only written at creation, so the copy may stay in flight
-    HIPCHK(hipMemcpyAsync(sk->d_thresh, &sk->t_init, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
     uint64_t c0 = next_pow2((uint64_t)sk->s * 64);
-    if (c0 < (256u << 10)) c0 = 256u << 10;
+    if (c0 < (1u << 20)) c0 = 1u << 20;
     if (sk->m > 1) c0 = kUncappedBytes; // multiplicity filter: the first stage is admitted whole (see push_device)
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
     sk->next_chunk_bytes = c0;
-    sk->settled = false;
-    sk->settled_total = 0;
     sk->bytes_pushed = 0;
     sk->hash_ms = 0.0;
     sk->launches = 0;
@@ -246,10 +249,15 @@ int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_byte
     A((void **)&sk->d_hist, kHistBins * sizeof(uint32_t));
     A((void **)&sk->d_acc, kAccReplicas * 8 * sizeof(uint64_t));
     A((void **)&sk->d_stats, kStatReplicas * kStatCount * sizeof(uint64_t));
-    A((void **)&sk->d_tickets, kMaxLaunchesPerPush * sizeof(uint32_t));
+    A((void **)&sk->d_tickets, kTicketWords * sizeof(uint32_t));
+    A((void **)&sk->d_done, sizeof(uint32_t));
     A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));
     A((void **)&sk->d_out_cnts, sk->out_cap * sizeof(uint32_t));
     A((void **)&sk->d_out_n, sizeof(uint32_t));
+    sk->fin_cap = (2 * s + 4096 + 1) & ~1u;
+    const size_t fin_bytes = (4 + (size_t)sk->fin_cap + sk->fin_cap / 2) * sizeof(uint64_t);
+    A((void **)&sk->d_fin, fin_bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sk->h_fin, fin_bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         free_sketcher(sk);
         return fail(MHX_E_HIP, "hipMalloc failed while creating the sketcher: %s", hipGetErrorString(e));
@@ -311,8 +319,6 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     const uint64_t ntiles64 = (a.end + kTileBytes - 1) / kTileBytes;
     if (ntiles64 > 0x7FFFFFFFull) return fail(MHX_E_ARG, "span too large for one push (%llu bytes)", (unsigned long long)n);
     const uint32_t ntiles = (uint32_t)ntiles64;
-    // more input than the settling decision assumed: tighten again before admitting it wholesale
-    if (sk->settled && sk->bytes_pushed + n > 2 * sk->settled_total) sk->settled = false;
     if (fmt == MHX_FMT_FASTQ4) {
         if (sk->tile_state_cap < ntiles) {
             HIPCHK(hipStreamSynchronize(g.stream));
@@ -323,7 +329,10 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             sk->tile_state_cap = ntiles;
         }
         HIPCHK(hipMemsetAsync(sk->d_tile_state, 0, (size_t)ntiles * sizeof(uint64_t), g.stream));
-        HIPCHK(hipMemsetAsync(sk->d_tickets, 0, kMaxLaunchesPerPush * sizeof(uint32_t), g.stream));
+        if (sk->tickets_used + kMaxLaunchesPerPush > kTicketWords) { // every launch takes a fresh, still zero word
+            HIPCHK(hipMemsetAsync(sk->d_tickets, 0, kTicketWords * sizeof(uint32_t), g.stream));
+            sk->tickets_used = 0;
+        }
     }
     a.tile_state = sk->d_tile_state;
     TableArgs ta = table_args(sk);
@@ -334,9 +343,16 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     while (tile < ntiles) {
         uint32_t take = ntiles - tile;
         const bool last_slot = launch == kMaxLaunchesPerPush - 1;
-        if (!sk->settled && !last_slot) {
+        // Two regimes.  FREE-RUNNING (no multiplicity filter, or T already follows solid hashes): launches grow x16 and a
+        // tighten pass follows each one on the stream; the host never looks at T, so nothing waits for a round trip.
+        // After a chunk of N k-mers T sits at the s-th smallest of them, hence the next, 16x larger chunk admits ~16 s
+        // occurrences (x the share of erroneous k-mers when m > 1): a few percent of the table whatever the input is.
+        // STAGED (m > 1 before s solid hashes exist): T is a host-imposed cap that follows the bytes seen, the host
+        // reads the tighten pass's verdict after every launch to learn when solid hashes have taken over.
+        const bool staged = sk->m > 1 && !sk->established;
+        if (!last_slot) {
             uint64_t chunk_bytes = sk->next_chunk_bytes;
-            if (sk->m > 1 && !sk->established) {
+            if (staged) {
                 // stages of the capped phase are defined on the bytes actually seen (pushes may be of any size):
                 // the uncapped first MiB, then never more than x4 cumulative growth per launch
                 const uint64_t rest_of_prefix = sk->bytes_pushed < kUncappedBytes ? kUncappedBytes - sk->bytes_pushed : 0;
@@ -345,7 +361,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
             const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
             if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
         }
-        if (sk->m > 1 && !sk->established) {
+        if (staged) {
             // Multiplicity filter: T cannot follow the data before s hashes with count >= m exist, and until
             // then every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is
             // admitted whole (small genomes and saturated k-mer spaces show their solid hashes there); after
@@ -373,7 +389,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         }
         a.tile0 = tile;
         a.ntiles = take;
-        a.ticket = sk->d_tickets + launch;
+        a.ticket = sk->d_tickets + sk->tickets_used++;
         if (g.profiling) HIPCHK(hipEventRecord(g.ev0, g.stream));
         HIPCHK(launch_hash(sk->k, fmt, a, g.stream));
         if (g.profiling) {
@@ -386,22 +402,23 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         ++sk->launches;
         ++launch;
         tile += take;
+        sk->table_dirty = true;
         sk->bytes_pushed = pushed_before + std::min<uint64_t>(n, (uint64_t)tile * kTileBytes); // real bytes, not whole tiles: callers may push tiny spans
-        if (!sk->settled) {
-            // tighten T from what has been seen, then decide whether the rest can go at once:
-            // expected admissions of everything still to come must fit an eighth of the table
-            HIPCHK(launch_tighten(ta, g.stream));
+        // tighten T from what has been seen (also after the last launch of a push: the next push starts from it).
+        // Sampled passes (big tables) leave the table marked dirty: finish() wants an exact one.
+        HIPCHK(launch_tighten(ta, g.stream));
+        if (ta.sample == 1) sk->table_dirty = false;
+        if (staged) {
             uint64_t T;
-            rc = read_threshold(sk, &T);
+            rc = read_threshold(sk, &T); // sets sk->established once the pass has lowered T from solid hashes
             if (rc) return rc;
-            const uint64_t total = sk->expected_bytes > sk->bytes_pushed ? sk->expected_bytes : (uint64_t)ntiles * kTileBytes;
-            const uint64_t remaining = total > sk->bytes_pushed ? total - sk->bytes_pushed : (uint64_t)(ntiles - tile) * kTileBytes;
-            const long double admit = (long double)remaining * ((long double)T / (long double)sk->hash_max);
-            // (with a multiplicity filter only once T comes from solid hashes: a host-imposed cap must keep
-            // following the input in x4 stages, or it would drop below the final s-th solid hash)
-            const bool may_settle = sk->m == 1 || sk->established;
-            if (may_settle && admit <= (long double)(sk->nslots / 8)) { sk->settled = true; sk->settled_total = total > sk->bytes_pushed ? total : sk->bytes_pushed; }
-            else sk->next_chunk_bytes *= (sk->m > 1 && !sk->established) ? 4 : kChunkGrowth; // x4 stages until solid hashes exist
+            sk->next_chunk_bytes = std::max<uint64_t>(sk->next_chunk_bytes, sk->bytes_pushed); // what free-running continues from
+        } else if (sk->next_chunk_bytes < (1ull << 40)) {
+            // a chunk G times everything before it admits ~G*s occurrences (times the share of erroneous k-mers
+            // under a multiplicity filter): G is what keeps that at a sixteenth (m > 1: a 64th) of the table
+            uint64_t G = sk->nslots / ((sk->m > 1 ? 64ull : 16ull) * sk->s);
+            G = std::min<uint64_t>(std::max<uint64_t>(G, kChunkGrowth), 256);
+            sk->next_chunk_bytes *= G;
         }
     }
     return MHX_OK;
@@ -531,7 +548,7 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
 {
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemsetAsync(sk->d_out_n, 0, sizeof(uint32_t), g.stream));
-        HIPCHK(launch_extract(table_args(sk), limit, min_count, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, nullptr, nullptr, g.stream));
+        HIPCHK(launch_extract(table_args(sk), limit, min_count, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, nullptr, nullptr, nullptr, nullptr, g.stream));
         uint32_t n = 0;
         HIPCHK(hipMemcpyAsync(&n, sk->d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -591,34 +608,34 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !hashes || !n_out) return fail(MHX_E_ARG, "null argument");
-    // One batch on the stream, one synchronisation: final tighten, extract with the threshold read on the
-    // device, then threshold, counters, entry count and the first entries come back together.
-    uint64_t T = 0;
-    uint32_t n = 0;
-    std::vector<uint64_t> hs(kStatReplicas * kStatCount);
-    const uint32_t first = std::min<uint32_t>(sk->out_cap, 2 * sk->s + 4096);
-    std::vector<uint64_t> keys(first);
-    std::vector<uint32_t> cnts(first);
-    HIPCHK(launch_tighten(table_args(sk), g.stream));
-    HIPCHK(hipMemsetAsync(sk->d_out_n, 0, sizeof(uint32_t), g.stream));
-    HIPCHK(launch_extract(table_args(sk), 0, sk->m, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, sk->d_out_n, nullptr, sk->d_thresh, g.stream));
-    HIPCHK(hipMemcpyAsync(&T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(hs.data(), sk->d_stats, hs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(&n, sk->d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(keys.data(), sk->d_out_keys, (size_t)first * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(cnts.data(), sk->d_out_cnts, (size_t)first * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    // One batch on the stream, one copy, one synchronisation: final (exact) tighten unless the last pass already was
+    // one, extract with the threshold read on the device into the result block, the block to its pinned mirror.
+    const uint32_t cap = sk->fin_cap;
+    uint64_t *d = sk->d_fin;
+    const size_t fin_bytes = (4 + (size_t)cap + cap / 2) * sizeof(uint64_t);
+    if (sk->table_dirty) {
+        HIPCHK(launch_tighten(table_args(sk), g.stream));
+        sk->table_dirty = false;
+    }
+    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), g.stream));
+    HIPCHK(launch_extract(table_args(sk), 0, sk->m, d + 4, (uint32_t *)(d + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3, g.stream));
+    HIPCHK(hipMemcpyAsync(sk->h_fin, d, fin_bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    const uint64_t *h = sk->h_fin;
+    const uint32_t n = (uint32_t)h[0];
+    const uint64_t T = h[1], flags = h[2], maxkey = h[3];
     sk->last_T = T;
-    uint64_t flags = 0, maxkey = 0;
-    for (int r = 0; r < kStatReplicas; ++r) { flags |= hs[r * kStatCount + kStatFlags]; maxkey += hs[r * kStatCount + kStatMaxKey]; }
     rc = check_flags(flags);
     if (rc) return rc;
-    if (n > first) { // more entries below T than the first copy covered (or than the device buffer holds)
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> cnts;
+    if (n > cap) { // more entries below T than the result block holds: the general path
         rc = extract(sk, T, sk->m, keys, cnts);
         if (rc) return rc;
     } else {
-        keys.resize(n);
-        cnts.resize(n);
+        keys.assign(h + 4, h + 4 + n);
+        const uint32_t *hc = reinterpret_cast<const uint32_t *>(h + 4 + cap);
+        cnts.assign(hc, hc + n);
     }
     if (T == ~0ull && maxkey >= sk->m) { // the one hash value the table cannot hold
         keys.push_back(~0ull);
@@ -679,11 +696,10 @@ extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t
     if (!sk || !d_slab || cap == 0 || (cap & 1)) return fail(MHX_E_ARG, "export_slab: null argument or odd capacity");
     uint64_t *w = (uint64_t *)d_slab;
     HIPCHK(hipMemsetAsync(w, 0, 3 * sizeof(uint64_t), g.stream));
-    HIPCHK(hipMemcpyAsync(w + 1, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
     // host-side state of the m > 1 phase rides in the flags word (the device flags are OR-ed in by the kernel)
     sk->slab_state = (sk->bounded ? (uint64_t)MHX_SLAB_BOUNDED : 0) | (sk->established ? (uint64_t)MHX_SLAB_ESTABLISHED : 0);
     if (sk->slab_state) HIPCHK(hipMemcpyAsync(w + 2, &sk->slab_state, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, g.stream));
+    HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, w + 1, nullptr, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
 }

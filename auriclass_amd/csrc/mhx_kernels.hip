@@ -4,7 +4,8 @@
 //                              stream: stage -> classify -> (FASTQ) decoupled look-back for
 //                              the line phase -> valid k-mer starts -> LDS work list ->
 //                              canonical k-mer + MurmurHash3_x64_128 -> admission -> table
-//   table_hist / table_select  tighten the admission threshold T from the candidate table
+//   table_tighten              tightens the admission threshold T from the candidate table (one launch)
+//   table_reset                vacates the table and clears the control buffers (one launch)
 //   table_extract              compact (hash,count) entries <= limit for the host / all-gather
 //   dist_pairs_kernel          mash compareSketches for a batch of (query, ref) pairs
 //
@@ -279,12 +280,19 @@ hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st)
 // s entries with count >= m already exist, so every hash of the final sketch stays admitted
 // (and therefore fully counted) for the whole run.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
+// One kernel: every workgroup histograms its share of the table in LDS and flushes it with global atomics; the
+// workgroup that finishes LAST (ticket) turns the histogram into the new threshold.  All cross-workgroup data moves
+// through memory-side atomics (the flush, the ticket) and agent-scope loads / stores in the last workgroup (which also
+// clear the bins for the next pass), with an agent-scope release in front of the ticket, so no cache of another XCD is
+// ever trusted.
+__global__ __launch_bounds__(256) void table_tighten_kernel(const TableArgs a)
 {
     __shared__ uint32_t h[kHistBins];
-    __shared__ uint32_t occ_s, solid_s;
+    __shared__ uint32_t occ_s, solid_s, last_s, cut_s;
+    __shared__ uint32_t wave_sums[4];
+    __shared__ unsigned long long tot_s[2];
     for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) h[i] = 0;
-    if (threadIdx.x == 0) { occ_s = 0; solid_s = 0; }
+    if (threadIdx.x == 0) { occ_s = 0; solid_s = 0; cut_s = 0xFFFFFFFFu; tot_s[0] = 0; tot_s[1] = 0; }
     __syncthreads();
     const uint64_t T = *a.thresh;
     const int lz = T ? __builtin_clzll(T) : 63;
@@ -318,55 +326,76 @@ __global__ __launch_bounds__(256) void table_hist_kernel(const TableArgs a)
     for (int i = threadIdx.x; i < kHistBins; i += blockDim.x)
         if (h[i]) atomicAdd(&a.hist[i], h[i]);
     if (threadIdx.x == 0) {
-        // 64 replicas, 64 bytes apart: a thousand workgroups adding to ONE word serialise at ~10-20 ns each,
-        // which was most of this kernel's 33 us
+        // 64 replicas, 64 bytes apart: a thousand workgroups adding to ONE word serialise at ~10-20 ns each
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.acc) + (blockIdx.x % kAccReplicas) * 8;
         if (occ_s) atomicAdd(&acc[0], (unsigned long long)occ_s);
         if (solid_s) atomicAdd(&acc[1], (unsigned long long)solid_s);
     }
-}
+    // every wave waits for its own atomics, the barrier collects the waves, ONE lane fences and takes the ticket
+    // (256 threads fencing cost 60 us per pass)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last_s = atomicAdd(a.done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
 
-__global__ __launch_bounds__(1024) void table_select_kernel(const TableArgs a)
-{
-    // one block: prefix over the histogram, first bin where the cumulative count reaches s
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t cut;
-    const int t = threadIdx.x;
-    const uint32_t c0 = a.hist[2 * t], c1 = a.hist[2 * t + 1];
-    part[t] = c0 + c1;
-    if (t == 0) cut = 0xFFFFFFFFu;
+    // ---- last workgroup: first bin where the cumulative count reaches s ----------------------------------------
+    // T only ever decreases, and only to a value below which at least s entries with count >= m already exist, so
+    // every hash of the final sketch stays admitted (and therefore fully counted) for the whole run.
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int kPer = kHistBins / 256; // bins per thread, in value order
+    uint32_t c[kPer], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { // agent-scope load + store: served past the caches, like the look-back words
+        c[j] = __hip_atomic_load(&a.hist[kPer * t + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.hist[kPer * t + j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine += c[j];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
     __syncthreads();
-    uint32_t before = 0;
-    for (int i = 0; i < t; ++i) before += part[i];
-    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += wave_sums[w];
     // sampled pass: counts are ~Binomial(truth, 1/sample); ask for the expected s/sample plus six
     // standard deviations (+16 for small s) so that the sampling error cannot push T below the true
-    // s-th qualifying hash (~1e-9 per pass; finish() re-checks exactly and refuses otherwise)
+    // s-th qualifying hash (~1e-9 per pass; finish() counts exactly and refuses a short result below a lowered T)
     uint32_t s = a.sketch_size;
     if (a.sample > 1) {
         const float mean = (float)a.sketch_size / (float)a.sample;
         s = (uint32_t)(mean + 6.0f * sqrtf(mean)) + 16u;
     }
-    if (before < s && before + c0 >= s) atomicMin(&cut, (uint32_t)(2 * t));
-    else if (before + c0 < s && before + c0 + c1 >= s) atomicMin(&cut, (uint32_t)(2 * t + 1));
-    a.hist[2 * t] = 0;
-    a.hist[2 * t + 1] = 0;
-    __syncthreads();
-    if (t == 0) { // publish this pass's totals (replica 0), clear the accumulators
-        uint64_t occ = 0, solid = 0;
-        for (int r = 0; r < kAccReplicas; ++r) {
-            occ += a.acc[r * 8];
-            solid += a.acc[r * 8 + 1];
-            a.acc[r * 8] = 0;
-            a.acc[r * 8 + 1] = 0;
+    if (before < s && before + mine >= s) { // the cut lies in one of my bins (exactly one thread gets here)
+        uint32_t run = before;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (run < s && run + c[j] >= s) cut_s = (uint32_t)(kPer * t + j);
+            run += c[j];
         }
-        a.stats[kStatOccupied] = occ * (a.sample > 1 ? a.sample : 1);
-        a.stats[kStatSolid] = solid * (a.sample > 1 ? a.sample : 1);
     }
-    if (t == 0 && cut != 0xFFFFFFFFu) {
-        const uint64_t T = *a.thresh;
-        const int lz = T ? __builtin_clzll(T) : 63;
-        if (lz <= 52) {
+    if (t < kAccReplicas) { // this pass's totals
+        uint64_t *acc = a.acc + t * 8;
+        const uint64_t o = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t so = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc[0], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc[1], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o) atomicAdd(&tot_s[0], (unsigned long long)o);
+        if (so) atomicAdd(&tot_s[1], (unsigned long long)so);
+    }
+    __syncthreads();
+    if (t == 0) {
+        a.stats[kStatOccupied] = tot_s[0] * (a.sample > 1 ? a.sample : 1);
+        a.stats[kStatSolid] = tot_s[1] * (a.sample > 1 ? a.sample : 1);
+        *a.done = 0;
+        const uint32_t cut = cut_s;
+        if (cut != 0xFFFFFFFFu && lz <= 52) {
             const uint64_t edge = (((uint64_t)cut + 1) << (53 - lz)) - 1; // last value of bin `cut`
             if (edge < T) *a.thresh = edge;
         }
@@ -391,16 +420,50 @@ hipError_t launch_tighten(const TableArgs &a, hipStream_t st)
     uint64_t blocks = a.nslots / 256 / 16;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(table_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(table_select_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(table_tighten_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// One launch instead of five memsets and a copy: vacates the table and clears every small control buffer.
+__global__ __launch_bounds__(256) void table_reset_kernel(const TableArgs a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n)
+{
+    const uint64_t n2 = a.nslots / 2, n4 = a.nslots / 4; // nslots is a power of two >= 2^16
+    uint4 *k4 = reinterpret_cast<uint4 *>(a.keys), *c4 = reinterpret_cast<uint4 *>(a.cnts);
+    const uint4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, zero = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) {
+        k4[i] = ones;
+        if (i < n4) c4[i] = zero;
+    }
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kHistBins; i += blockDim.x) a.hist[i] = 0;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kAccReplicas * 8; i += blockDim.x) a.acc[i] = 0;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(kStatReplicas * kStatCount); i += blockDim.x) a.stats[i] = 0;
+        for (uint32_t i = threadIdx.x; i < ntickets; i += blockDim.x) tickets[i] = 0;
+        if (threadIdx.x == 0) { *a.thresh = t_init; *a.done = 0; *out_n = 0; }
+    }
+}
+
+hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n, hipStream_t st)
+{
+    uint64_t blocks = a.nslots / 2 / 256 / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(table_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, t_init, tickets, ntickets, out_n);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, uint64_t limit, uint32_t min_count,
                                                             uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
-                                                            uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev)
+                                                            uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
+                                                            uint64_t *limit_out, uint64_t *maxkey_out)
 {
     if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
+    if (blockIdx.x == 0 && threadIdx.x == 0 && limit_out) *limit_out = limit;
+    // optional: occurrences of the one hash value the table cannot hold (2^64 - 1), summed over the replicas
+    if (maxkey_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
+        const uint64_t c = a.stats[threadIdx.x * kStatCount + kStatMaxKey];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long *>(maxkey_out), (unsigned long long)c);
+    }
     // optional: OR of the replicated device flags, so that a caller that never reads the stats block
     // (the multi-GPU slab export) still learns about a full table or a malformed FASTQ
     if (flags_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
@@ -448,12 +511,13 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
 }
 
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
-                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev, hipStream_t st)
+                          uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
-                       out_cnts, cap, out_n, flags_out, limit_dev);
+                       out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out);
     return hipGetLastError();
 }
 
