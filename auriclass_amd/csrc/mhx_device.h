@@ -47,6 +47,13 @@ hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st);
 bool hash_k_supported(int k);
 
+// FASTA on the device (mhx_fasta.hip): raw file bytes -> dense sequence stream + record separator positions.
+// ws: fasta_workspace_bytes(n) bytes; after the launch *(uint64_t *)(ws + o_off + 8 * ntiles) is the stream size,
+// ((uint32_t *)(ws + o_flags))[0] the format flag (1: FASTQ syntax seen), [1] the number of separators.
+constexpr int kFastaTile = 16384;
+size_t fasta_workspace_bytes(uint64_t n, size_t *o_summary, size_t *o_in, size_t *o_off, size_t *o_flags);
+hipError_t launch_fasta_compact(const uint8_t *base, uint64_t n, uint8_t *ws, uint8_t *out, uint64_t *seps, uint32_t seps_cap, hipStream_t st);
+
 struct DistArgs {
     const uint64_t *q;
     const uint32_t *q_len;

@@ -667,6 +667,114 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     return rc;
 }
 
+// ---- FASTA through the device parser ------------------------------------------------------------------------
+// `mash sketch` without -r: one reference per file (auriclass/classes.py:696-713).  The inflated file goes to the GPU
+// as it is; mhx_fasta.hip squeezes it into the dense sequence stream (header lines dropped, line breaks removed inside a
+// record, one separator byte in front of every record) and notes where the records start, the sketch kernel hashes the
+// stream.  The host only looks at the record start positions (lengths, the count of records of >= k bases, the first
+// of them for the reference's name).  Returns kFastaNotForDevice when the file is not plain FASTA (does not start
+// with '>', or holds FASTQ syntax): the caller then takes the host record parser, as before.
+namespace {
+constexpr int kFastaNotForDevice = 1;
+
+struct FastaInfo {
+    uint64_t records = 0, total_length = 0;
+    std::string first_name, first_comment;
+};
+
+struct DeviceBuf {
+    void *p = nullptr;
+    ~DeviceBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+};
+
+// header line number `idx` (0-based, counting lines that start with '>') of a FASTA held in memory
+bool nth_header(const uint8_t *b, size_t n, uint64_t idx, std::string &name, std::string &comment)
+{
+    size_t p = 0;
+    uint64_t seen = 0;
+    while (p < n) {
+        const uint8_t *e = (const uint8_t *)memchr(b + p, '\n', n - p);
+        const size_t le = e ? (size_t)(e - b) : n;
+        if (b[p] == '>') {
+            if (seen == idx) { first_header(b + p, le - p, name, comment); return true; }
+            ++seen;
+        }
+        p = le + 1;
+    }
+    return false;
+}
+} // namespace
+
+static int sketch_fasta_on_device(const std::vector<uint8_t> &raw, int k, uint32_t s, std::vector<uint64_t> &hashes, FastaInfo &info)
+{
+    const uint64_t n = raw.size();
+    if (n == 0 || raw[0] != '>' || n > 0x7FFFFFFF00ull) return kFastaNotForDevice;
+    size_t os, oi, oo, of;
+    const size_t ws_bytes = fasta_workspace_bytes(n, &os, &oi, &oo, &of);
+    const uint64_t ntiles = (n + kFastaTile - 1) / kFastaTile;
+    DeviceBuf d_raw, d_out, d_ws, d_seps;
+    uint32_t seps_cap = (uint32_t)std::min<uint64_t>(n / 2 + 16, 1u << 20);
+    if (d_raw.alloc(n + 64) != hipSuccess || d_out.alloc(n + 64) != hipSuccess || d_ws.alloc(ws_bytes) != hipSuccess ||
+        d_seps.alloc((size_t)seps_cap * 8) != hipSuccess)
+        return fail(MHX_E_HIP, "hipMalloc failed for the FASTA buffers (%llu bytes)", (unsigned long long)n);
+    HIPCHK(hipMemcpyAsync(d_raw.p, raw.data(), n, hipMemcpyHostToDevice, g.stream));
+    uint64_t total = 0;
+    uint32_t fl[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(launch_fasta_compact((const uint8_t *)d_raw.p, n, (uint8_t *)d_ws.p, (uint8_t *)d_out.p, (uint64_t *)d_seps.p, seps_cap, g.stream));
+        HIPCHK(hipMemcpyAsync(&total, (uint8_t *)d_ws.p + oo + 8 * ntiles, 8, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipMemcpyAsync(fl, (uint8_t *)d_ws.p + of, 8, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (fl[0] & 1u) return kFastaNotForDevice;
+        if (fl[1] <= seps_cap) break;
+        if (attempt) return fail(MHX_E_INTERNAL, "FASTA record list kept growing");
+        seps_cap = fl[1] + 16; // more records than the first guess: once more with room for all of them
+        hipFree(d_seps.p);
+        d_seps.p = nullptr;
+        if (d_seps.alloc((size_t)seps_cap * 8) != hipSuccess) return fail(MHX_E_HIP, "hipMalloc failed for %u FASTA record positions", seps_cap);
+    }
+    // records: separator i sits in front of record i; its length is the distance to the next separator (or the end)
+    std::vector<uint64_t> seps(fl[1]);
+    if (!seps.empty()) {
+        HIPCHK(hipMemcpyAsync(seps.data(), d_seps.p, seps.size() * 8, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        std::sort(seps.begin(), seps.end());
+    }
+    info = FastaInfo();
+    uint64_t first_counted = ~0ull;
+    for (size_t i = 0; i < seps.size(); ++i) {
+        const uint64_t len = (i + 1 < seps.size() ? seps[i + 1] : total) - seps[i] - 1;
+        if (len >= (uint64_t)k) {
+            if (first_counted == ~0ull) first_counted = i;
+            ++info.records;
+            info.total_length += len;
+        }
+    }
+    // a last header line without its newline has no separator and no sequence: it does not count either way
+    if (info.records == 0) return MHX_OK; // the caller reports "Did not find fasta records"
+    nth_header(raw.data(), raw.size(), first_counted, info.first_name, info.first_comment);
+    uint64_t boost = 1;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        mhx_sketcher *sk = nullptr;
+        int rc = create_sketcher(k, s, 1, total, boost, &sk);
+        if (rc) return rc;
+        rc = mhx_sketcher_push_device(sk, d_out.p, total, MHX_FMT_SEQ);
+        uint32_t nh = 0;
+        std::vector<uint32_t> counts(s);
+        if (!rc) {
+            hashes.resize(s);
+            rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &nh);
+        }
+        mhx_sketcher_destroy(sk);
+        if (rc == MHX_E_CAPACITY) { boost *= 16; continue; }
+        if (rc) return rc;
+        hashes.resize(nh);
+        return MHX_OK;
+    }
+    return fail(MHX_E_CAPACITY, "could not size the device table for this input");
+}
+
 static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
                                 const char *out_msh, char *stderr_buf, size_t stderr_cap, size_t *stderr_need,
                                 double *est_genome_size)
@@ -764,6 +872,21 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
             err += std::string("Sketching ") + paths[i] + "...\n";
             rc = read_all_maybe_gz(paths[i], loaded[i].raw);
             if (rc) return rc;
+            if (!getenv("MHX_HOST_FASTA")) { // plain FASTA: parsed on the device
+                RefSketch ref;
+                FastaInfo info;
+                rc = sketch_fasta_on_device(loaded[i].raw, k, s, ref.hashes, info);
+                if (rc < 0) return rc;
+                if (rc == MHX_OK) {
+                    if (info.records == 0) return no_records(paths[i]);
+                    ref.name = paths[i];
+                    ref.comment = make_comment(info.first_name, info.first_comment, info.records);
+                    ref.length = info.total_length;
+                    set.refs.push_back(std::move(ref));
+                    loaded[i] = Loaded();
+                    continue;
+                }
+            }
             rc = parse_fastx(loaded[i].raw.data(), loaded[i].raw.size(), k, loaded[i].rec);
             if (rc) return rc;
             if (loaded[i].rec.records == 0) return no_records(paths[i]);
