@@ -182,6 +182,63 @@ def test_K3_K4_fastq_workflow_rows(refcwd, golden):
     assert out.read_bytes() == mo.msh_bytes(osk)
 
 
+def test_estimated_coverage_line_is_the_mean_exact_multiplicity(refcwd):
+    """`Estimated coverage:` (re-logged by /root/reference/auriclass/classes.py:602-606, never parsed): mash prints the mean
+    of its heap's counters, which miss repeats of the heap's current maximum and so depend on the input order (the oracle
+    reproduces that: 39.125 on the fixture); the engine prints the mean of the EXACT multiplicities of the sketch's
+    hashes.  Stated in INTEGRATION.md section 2; this pins the engine's definition and its relation to mash's."""
+    import gzip
+
+    files = ["tests/data/NC_001416.1_1.fq.gz", "tests/data/NC_001416.1_2.fq.gz"]
+    stderr, _ = engine.sketch_files(files, 27, 50000, refcwd / "c.msh", reads=True, min_mult=3)
+    line = [l for l in stderr.splitlines() if l.startswith("Estimated coverage:")]
+    assert len(line) == 1 and line[0].startswith("Estimated coverage:    ")
+    got = float(line[0].split()[-1])
+    reads = []
+    for f in files:
+        rec = gzip.open(f, "rb").read().split(b"\n")
+        reads += rec[1::4]
+    hashes, counts = mo.bruteforce_sketch(reads, 27, 50000, 3)
+    assert line[0] == "Estimated coverage:    " + mo.fmt_g(counts.sum() / len(hashes))
+    osk_sketcher = mo.Sketcher(27, 50000, 3)
+    for f in files:
+        osk_sketcher.add_fastx(gzip.open(f, "rb").read())
+    osk_sketcher.finish()
+    assert got >= osk_sketcher.multiplicity > 0.9 * got   # mash's figure is a slight under-count of the same quantity
+
+
+def test_third_party_sketch_containers_reference_list_and_counts(tmp_path):
+    """`.msh` files this engine did not write (docs/reference_genomes.md:3: the bundled clade references come from
+    elsewhere): a hash seed other than 42 moves the references to the `referenceList` pointer (the root's fourth) and
+    `mash sketch -M` adds a counts32 list to every reference.  Both must read back to the same distance table."""
+    rng = np.random.default_rng(99)
+
+    def refs(n, hi, with_counts):
+        out = []
+        for i in range(n):
+            h = np.unique(rng.integers(0, hi, size=int(rng.integers(200, 1500)), dtype=np.uint64))
+            c = rng.integers(1, 200, size=len(h)).astype(np.uint32) if with_counts else None
+            out.append(mo.Reference("ref%d.fa" % i, "comment %d" % i, int(rng.integers(1000, 10 ** 7)), h, c))
+        return out
+
+    for k, seed, with_counts in ((21, 7, False), (21, 42, True), (27, 1234567, True), (16, 3, True)):
+        hi = 2 ** 32 if k <= 16 else 2 ** 64
+        shared = refs(3, hi, with_counts)
+        R = mo.SketchFile(kmer_size=k, sketch_size=1000, hash_seed=seed, references=shared + refs(2, hi, with_counts))
+        Q = mo.SketchFile(kmer_size=k, sketch_size=1000, hash_seed=seed, references=refs(2, hi, with_counts) + shared[:1])
+        (tmp_path / "r.msh").write_bytes(mo.msh_bytes(R))
+        (tmp_path / "q.msh").write_bytes(mo.msh_bytes(Q))
+        assert engine.dist_files(tmp_path / "r.msh", tmp_path / "q.msh") == mo.dist_text(R, Q), (k, seed, with_counts)
+    # different seeds: mash refuses to compare, so does the engine
+    A = mo.SketchFile(kmer_size=21, sketch_size=1000, hash_seed=7, references=refs(1, 2 ** 64, False))
+    B = mo.SketchFile(kmer_size=21, sketch_size=1000, hash_seed=42, references=refs(1, 2 ** 64, False))
+    (tmp_path / "a.msh").write_bytes(mo.msh_bytes(A))
+    (tmp_path / "b.msh").write_bytes(mo.msh_bytes(B))
+    with pytest.raises(engine.EngineError) as e:
+        engine.dist_files(tmp_path / "a.msh", tmp_path / "b.msh")
+    assert e.value.code == engine.MHX_E_MISMATCH
+
+
 def test_K5_fasta_workflow_rows(refcwd):
     out = refcwd / "q.msh"
     engine.sketch_files(["tests/data/NC_001416.1.fasta.gz"], 27, 50000, out)
