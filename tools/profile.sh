@@ -23,4 +23,5 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
 done
 cd $R
 python3 tools/summarize_prof.py gpurun_out/prof gpurun_out/prof/summary $STEPS
+find $OUT -name "*counter_collection.csv" -delete   # the summary has what is kept
 echo profile done
