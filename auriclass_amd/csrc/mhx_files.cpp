@@ -284,7 +284,7 @@ class CrcFollower {
 // Producer of one input file: inflates it (own DEFLATE decoder on the whole compressed file in memory;
 // MHX_ZLIB_INFLATE=1 selects zlib's gzread instead; an uncompressed file is simply read) and cuts the
 // stream into record-aligned chunks.
-void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, FileIngestState *st)
+void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threads, ChunkQueue *q, FileIngestState *st)
 {
     const bool gz = is_gzip_file(path);
     const bool own = gz && !force_zlib && !getenv("MHX_ZLIB_INFLATE");
@@ -293,9 +293,17 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
     std::vector<uint8_t> zbytes;
     GzInflater inf;
     std::unique_ptr<CrcFollower> crc_thread; // own decoder only: the CRC pass runs beside the decoding, not after it
+    // a big single-member .gz (what sequencers write) is decoded by several threads (mhx_pinflate.cpp); what follows its
+    // first member, small files and anything the parallel decoder declines go through the sequential decoder
+    std::unique_ptr<ParallelGunzip> par;
     if (own) {
         if (!read_whole_file(path, zbytes, GzInflater::kInputPad)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
-        inf.set_input(zbytes.data(), zbytes.size() - GzInflater::kInputPad);
+        const size_t zn = zbytes.size() - GzInflater::kInputPad;
+        if (decode_threads >= 2) {
+            par.reset(new ParallelGunzip());
+            if (!par->start(zbytes.data(), zn, decode_threads)) par.reset();
+        }
+        inf.set_input(zbytes.data(), zn);
         if (!getenv("MHX_INLINE_CRC")) { inf.set_deferred_crc(true); crc_thread.reset(new CrcFollower()); }
     } else if (gz) {
         g = gzopen(path, "rb");
@@ -329,7 +337,20 @@ void inflate_fastq(const char *path, int file, bool force_zlib, ChunkQueue *q, F
         bool eof = false;
         while (n < kIngestChunk) {
             long got;
-            if (own) {
+            if (par) {
+                const size_t r = par->read(d + n, kIngestChunk - n);
+                if (r == (size_t)-1) got = -1;
+                else if (r == 0) { // end of the first member (CRC and length verified): the rest, if any, sequentially
+                    const size_t off = par->consumed_input(), zn = zbytes.size() - GzInflater::kInputPad;
+                    par.reset();
+                    inf.set_input(zbytes.data() + off, zn - off);
+                    produced = 0;
+                    continue;
+                } else {
+                    got = (long)r;
+                    produced += r;
+                }
+            } else if (own) {
                 const uint64_t hist = produced < GzInflater::kWindow ? produced : GzInflater::kWindow;
                 // pieces of 1 MiB when the CRC follows on its own thread (it reads them while they are still in cache)
                 const size_t want = crc_thread ? std::min<size_t>(kIngestChunk - n, 1u << 20) : kIngestChunk - n;
@@ -606,7 +627,12 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         ChunkQueue q;
         std::vector<std::thread> threads;
         for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
-        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, &q, &st[i]);
+        // decoding threads per .gz file: the host's share (MHX_INGEST_THREADS, default 16 = the CPU share of a 1-GPU box)
+        // split over the files that are inflated side by side
+        int budget = 16;
+        if (const char *e = getenv("MHX_INGEST_THREADS")) budget = atoi(e);
+        const int per_file = std::max(1, budget / (int)std::max<size_t>(1, queued.size()) - 1);
+        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, per_file, &q, &st[i]);
         IngestChunk c;
         while (q.get(c)) {
             if (rc) continue; // drain

@@ -78,6 +78,27 @@ class GzInflater {
 };
 uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n);
 
+// ---- one gzip member decoded by several threads (mhx_pinflate.cpp) -----------------------------------------------
+class ParallelGunzip {
+  public:
+    ParallelGunzip();
+    ~ParallelGunzip();
+    ParallelGunzip(const ParallelGunzip &) = delete;
+    ParallelGunzip &operator=(const ParallelGunzip &) = delete;
+    // The compressed file (GzInflater::kInputPad readable bytes behind data[n - 1]).  false: not worth it or not possible
+    // (small input, no second block start found, not gzip): use the sequential GzInflater.
+    bool start(const uint8_t *data, size_t n, int threads);
+    // Output of the FIRST member, in order: bytes copied, 0 at its end (CRC-32 and length verified), (size_t)-1 on error.
+    size_t read(uint8_t *dst, size_t want);
+    // after the end: offset just behind the member's trailer (further members / padding follow there)
+    size_t consumed_input() const;
+    const std::string &error() const;
+
+  private:
+    struct Impl;
+    Impl *impl_;
+};
+
 // ---- statistics / text (mhx_text.cpp) ---------------------------------------------------
 double binomial_cdf(uint64_t x, double p, uint64_t n);        // P[X <= x]
 double binomial_sf_ge(uint64_t x, double p, uint64_t n);      // P[X >= x]

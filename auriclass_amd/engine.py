@@ -111,6 +111,7 @@ def load() -> ctypes.CDLL:
                                 u64p, c.POINTER(u64p), u32p]
     L.mhx_sketcher_export_slab.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32]
     L.mhx_gunzip_buffer.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t)]
+    L.mhx_gunzip_buffer_mt.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_int]
     _lib = L
     return L
 
@@ -302,15 +303,30 @@ class Sketcher:
             return hashes[:n.value].copy(), counts[:n.value].copy()
 
 
-def gunzip(data: bytes) -> bytes:
-    """Inflate an in-memory .gz (all members) with the ingest's own DEFLATE decoder (host code, no GPU)."""
+def gunzip(data: bytes, threads: int = 1, size_hint: int = 0) -> bytes:
+    """Inflate an in-memory .gz (all members) with the ingest's own DEFLATE decoder (host code, no GPU);
+    threads > 1: the first member is decoded by that many threads (mhx_gunzip_buffer_mt)."""
     L = load()
     need = ctypes.c_size_t(0)
-    rc = L.mhx_gunzip_buffer(data, len(data), None, 0, ctypes.byref(need))
-    if rc:
-        raise EngineError(rc, L.mhx_last_error().decode())
+
+    def call(buf, cap):
+        if threads > 1:
+            return L.mhx_gunzip_buffer_mt(data, len(data), buf, cap, ctypes.byref(need), threads)
+        return L.mhx_gunzip_buffer(data, len(data), buf, cap, ctypes.byref(need))
+
+    if size_hint:
+        out = ctypes.create_string_buffer(size_hint)
+        rc = call(out, size_hint)
+        if rc == MHX_OK:
+            return out.raw[:need.value]
+        if rc != MHX_E_CAPACITY:
+            raise EngineError(rc, L.mhx_last_error().decode())
+    else:
+        rc = call(None, 0)
+        if rc:
+            raise EngineError(rc, L.mhx_last_error().decode())
     out = ctypes.create_string_buffer(max(1, need.value))
-    rc = L.mhx_gunzip_buffer(data, len(data), out, need.value, ctypes.byref(need))
+    rc = call(out, need.value)
     if rc:
         raise EngineError(rc, L.mhx_last_error().decode())
     return out.raw[:need.value]

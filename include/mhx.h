@@ -169,6 +169,10 @@ int mhx_msh_write(const char *path, int k, uint32_t s, uint32_t n_refs, const ch
  * (kseq's gzread inside `mash sketch`, auriclass/classes.py:588).  out == NULL or cap too small:
  * *out_n still receives the inflated size (MHX_E_CAPACITY in the second case). */
 int mhx_gunzip_buffer(const void *gz, size_t n, void *out, size_t cap, size_t *out_n);
+/* The same with `threads` decoding threads on the first gzip member (block-boundary search, symbolic decoding of the
+ * unknown 32 KiB windows, resolution; the result is byte-identical or the call fails); small inputs and threads < 2 take
+ * the sequential decoder. */
+int mhx_gunzip_buffer_mt(const void *gz, size_t n, void *out, size_t cap, size_t *out_n, int threads);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,30 @@ static long run_case(const uint8_t *z, size_t n, bool deferred)
     return total;
 }
 
+// the same input through the parallel decoder (mhx_pinflate.cpp); -1 refused, -2 declined (falls to the sequential decoder)
+static long run_par_case(const uint8_t *z, size_t n, int threads)
+{
+    uint8_t *in = (uint8_t *)malloc(n + GzInflater::kInputPad);
+    memcpy(in, z, n);
+    memset(in + n, 0, GzInflater::kInputPad);
+    long total = 0;
+    {
+        mhx::ParallelGunzip par;
+        if (!par.start(in, n, threads)) total = -2;
+        else {
+            std::vector<uint8_t> piece(1u << 16);
+            for (;;) {
+                const size_t got = par.read(piece.data(), piece.size());
+                if (got == (size_t)-1) { total = -1; break; }
+                if (got == 0) break;
+                total += (long)got;
+            }
+        }
+    }
+    free(in);
+    return total;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) return 2;
@@ -74,10 +98,13 @@ int main(int argc, char **argv)
     fclose(f);
     const long mutations = atol(argv[2]);
     rng_state = (uint64_t)atoll(argv[3]) * 2 + 1;
-    long ok = 0, refused = 0;
+    long ok = 0, refused = 0, par_ok = 0, par_refused = 0, par_declined = 0;
     auto tally = [&](long v) { if (v < 0) ++refused; else ++ok; };
-    // 1. the seed itself must decode
-    if (run_case(seed.data(), seed.size(), false) < 0) { fprintf(stderr, "seed refused\n"); return 3; }
+    // 1. the seed itself must decode, both ways, to the same length
+    const long seed_len = run_case(seed.data(), seed.size(), false);
+    if (seed_len < 0) { fprintf(stderr, "seed refused\n"); return 3; }
+    const long par_len = run_par_case(seed.data(), seed.size(), 3);
+    if (par_len != -2 && par_len > seed_len) { fprintf(stderr, "parallel decoder produced more than the member holds\n"); return 5; }
     // 2. crafted: 10-byte header + a stored block + the start of another stored block whose LEN/NLEN lie in the pad
     {
         const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
@@ -113,7 +140,11 @@ int main(int argc, char **argv)
         size_t n = y.size();
         if (rnd() % 4 == 0) n = (size_t)(rnd() % (y.size() + 1));
         tally(run_case(y.data(), n, (i & 1) != 0));
+        if (i % 4 == 0) { // refused, declined or decoded: no out-of-bounds access either way
+            const long pr = run_par_case(y.data(), n, 2 + (int)(i % 3));
+            if (pr == -2) ++par_declined; else if (pr == -1) ++par_refused; else ++par_ok;
+        }
     }
-    printf("ok %ld refused %ld\n", ok, refused);
+    printf("ok %ld refused %ld parallel: ok %ld refused %ld declined %ld (seed: %ld)\n", ok, refused, par_ok, par_refused, par_declined, par_len);
     return 0;
 }
