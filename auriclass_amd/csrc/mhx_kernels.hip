@@ -348,9 +348,12 @@ __global__ __launch_bounds__(256) void table_tighten_kernel(const TableArgs a)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     constexpr int kPer = kHistBins / 256; // bins per thread, in value order
     uint32_t c[kPer], mine = 0;
+    // agent-scope loads + stores: served past the caches, like the look-back words.  All loads first (one round trip for
+    // the eight of them instead of eight), then the stores that clear the bins for the next pass.
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) { // agent-scope load + store: served past the caches, like the look-back words
-        c[j] = __hip_atomic_load(&a.hist[kPer * t + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < kPer; ++j) c[j] = __hip_atomic_load(&a.hist[kPer * t + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
         __hip_atomic_store(&a.hist[kPer * t + j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mine += c[j];
     }

@@ -117,12 +117,26 @@ MHX_HD uint32_t funnel_bits(uint32_t hi, uint32_t lo, uint32_t bit_shift)
 #endif
 }
 
+// 0x80 in every byte of v that equals the byte replicated in `pattern` (exact).  One instruction less than
+// zero_byte_flags(v ^ pattern): the xor-ed word itself is never needed, only its low seven bits per byte (one v_bitop3:
+// (v ^ pattern) & 0x7F7F7F7F) and its top bits, which for patterns below 0x80 are v's own top bits.
+MHX_HD uint32_t byte_eq_flags(uint32_t v, uint32_t pattern)
+{
+    const uint32_t t = ((v ^ pattern) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | v) & 0x80808080u;
+}
+// flags (0x80 per byte) of two consecutive dwords -> 8 mask bits, low dword first, with ONE multiplication: the first
+// dword's flags move to bit 3 of each byte, the second's stay at bit 7; times 0x00204081 the eight flags land in bits
+// 24..31 in byte order (the stray partial products fall on distinct bits below 24 or beyond 31, so nothing carries).
+MHX_HD uint32_t flags_to_byte(uint32_t f_lo, uint32_t f_hi) { return (((f_lo >> 4) | f_hi) * 0x00204081u) >> 24; }
+
 // newline mask of one 32-byte word (8 dwords at p)
 MHX_HD uint32_t newline_mask(const uint32_t *p)
 {
     uint32_t n = 0;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) n |= flags_to_nibble(zero_byte_flags(p[d] ^ 0x0A0A0A0Au)) << (4 * d);
+    for (int d = 0; d < 8; d += 2)
+        n |= flags_to_byte(byte_eq_flags(p[d], 0x0A0A0A0Au), byte_eq_flags(p[d + 1], 0x0A0A0A0Au)) << (4 * d);
     return n;
 }
 // A/C/G/T (either case) mask of the four bytes of a dword, as flags 0x80 per byte
