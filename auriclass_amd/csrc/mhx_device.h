@@ -41,7 +41,7 @@ struct TableArgs {
 hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st);
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st);
 hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n, hipStream_t st);
-hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, hipStream_t st);
+hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, uint64_t *stats, hipStream_t st);
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st);

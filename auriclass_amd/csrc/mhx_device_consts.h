@@ -27,6 +27,9 @@ constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // vacant slot of the cand
 constexpr uint64_t kFlagTableFull = 1;   // probe limit hit: result not exact, retry bigger
 constexpr uint64_t kFlagBadFastq = 2;    // a record violated the 4-line layout
 constexpr uint64_t kFlagSpinTimeout = 4; // look-back spin bound hit (should never happen)
+// state bits the extract kernel adds to the flags word it reports (same values as MHX_SLAB_* of include/mhx.h)
+constexpr uint64_t kFlagStateBounded = 0x100, kFlagStateEstablished = 0x200;
+constexpr uint64_t kFlagErrorMask = 0xFF;
 
 enum Stat : int {
     kStatKmers = 0,   // windows hashed: k-mer starts with K bytes inside one sequence line / record (A/C/G/T or not)
@@ -37,7 +40,9 @@ enum Stat : int {
     kStatOccupied = 5,
     kStatSolid = 6,   // entries <= T with count >= m seen by the last tighten pass
     kStatRecords = 7, // FASTQ records whose sequence line holds >= k bytes (mash's sequence count)
-    kStatStamp0 = 8,  // diagnostic builds (-DMHX_STAMPS): cycles per phase, summed over workgroups
+    kStatStamp0 = 8,  // diagnostic builds (-DMHX_STAMPS): cycles per phase, summed over workgroups (8..13)
+    kStatEstablished = 14, // replica 0 only, m > 1: a tighten pass has lowered T from solid (count >= m) hashes
+    kStatBounded = 15,     // replica 0 only, m > 1: the byte-count cap has limited T at least once
     kStatCount = 16
 };
 constexpr int kStatReplicas = 64; // counters are replicated to spread atomic traffic

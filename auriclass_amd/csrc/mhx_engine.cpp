@@ -146,11 +146,10 @@ struct mhx_sketcher {
     uint64_t last_T = 0;
     // m > 1 only: until s hashes with count >= m exist below T the table is protected by a bound that
     // follows the input seen so far (see push_device)
-    bool bounded = false;      // a host-imposed bound has limited T at least once
-    bool established = false;  // the tighten pass has lowered T from solid (count >= m) entries
+    bool bounded = false;      // as of the last finish(): the byte-count cap has limited T at least once (m > 1)
+    bool established = false;  // as of the last finish(): a tighten pass has lowered T from solid (count >= m) entries
     uint64_t occupied = 0;     // table occupancy reported by the last tighten pass
     uint64_t solid = 0;        // entries <= T with count >= m reported by the last tighten pass
-    uint64_t slab_state = 0;   // staging word of export_slab (MHX_SLAB_* bits)
 };
 
 static constexpr int kMaxLaunchesPerPush = 64;
@@ -291,7 +290,6 @@ static int read_threshold(mhx_sketcher *sk, uint64_t *T)
     HIPCHK(hipMemcpyAsync(T, sk->d_thresh, sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipMemcpyAsync(occ_solid, sk->d_stats + kStatOccupied, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (*T < sk->last_T && sk->m > 1) sk->established = true; // only the tighten pass lowers T between host writes
     sk->last_T = *T;
     sk->occupied = occ_solid[0];
     sk->solid = occ_solid[1];
@@ -343,47 +341,41 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     while (tile < ntiles) {
         uint32_t take = ntiles - tile;
         const bool last_slot = launch == kMaxLaunchesPerPush - 1;
-        // Two regimes.  FREE-RUNNING (no multiplicity filter, or T already follows solid hashes): launches grow x16 and a
-        // tighten pass follows each one on the stream; the host never looks at T, so nothing waits for a round trip.
-        // After a chunk of N k-mers T sits at the s-th smallest of them, hence the next, 16x larger chunk admits ~16 s
-        // occurrences (x the share of erroneous k-mers when m > 1): a few percent of the table whatever the input is.
-        // STAGED (m > 1 before s solid hashes exist): T is a host-imposed cap that follows the bytes seen, the host
-        // reads the tighten pass's verdict after every launch to learn when solid hashes have taken over.
-        const bool staged = sk->m > 1 && !sk->established;
+        // The host never looks at T while pushing: every launch is followed by a tighten pass on the stream and nothing
+        // waits for a round trip.
+        // No multiplicity filter: launches grow by a factor G.  After a chunk of N k-mers T sits at the s-th smallest of
+        // them, hence the next, G times larger chunk admits ~G*s occurrences: G is what keeps that at a sixteenth of the
+        // table whatever the input is.
+        // Multiplicity filter (m > 1): T cannot follow the data before s hashes with count >= m exist, and until then
+        // every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is admitted whole (small
+        // genomes and saturated k-mer spaces show their solid hashes there); after that the bytes seen grow x4 per launch
+        // and, in front of every launch, T is capped ON THE DEVICE at 48*s' / (bytes seen after this launch),
+        // s' = s + 8*sqrt(s) + 16, i.e. ~20*s admissions per stage -- unless a tighten pass has meanwhile lowered T from
+        // solid hashes, or the table looks like a small genome sequenced deeply (cap_threshold_kernel).  The cap stays
+        // above the final s-th solid hash for any genome size while the error-free k-mer coverage c so far is <= ~17x,
+        // and s solid hashes appear below it as soon as c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window
+        // no x4 stage can jump over.  Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s
+        // exactness check and the retry with a 16x budget.
+        const bool filtered = sk->m > 1;
         if (!last_slot) {
             uint64_t chunk_bytes = sk->next_chunk_bytes;
-            if (staged) {
-                // stages of the capped phase are defined on the bytes actually seen (pushes may be of any size):
-                // the uncapped first MiB, then never more than x4 cumulative growth per launch
+            if (filtered) {
+                // stages are defined on the bytes actually seen (pushes may be of any size): the uncapped first MiB,
+                // then never more than x4 cumulative growth per launch
                 const uint64_t rest_of_prefix = sk->bytes_pushed < kUncappedBytes ? kUncappedBytes - sk->bytes_pushed : 0;
                 chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * sk->bytes_pushed);
             }
             const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
             if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
         }
-        if (staged) {
-            // Multiplicity filter: T cannot follow the data before s hashes with count >= m exist, and until
-            // then every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is
-            // admitted whole (small genomes and saturated k-mer spaces show their solid hashes there); after
-            // that T is capped at 48*s' / (bytes seen after this launch), s' = s + 8*sqrt(s) + 16, i.e. ~20*s
-            // admissions per x4 stage.  The cap stays above the final s-th solid hash for any genome size while
-            // the error-free k-mer coverage c so far is <= ~17x, and s solid hashes appear below it as soon as
-            // c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window no x4 stage can jump over.
-            // Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s exactness check and
-            // the retry with a 16x budget.
-            // No cap while the input looks like a small genome sequenced deeply (a fifth of the table entries
-            // are solid already, yet fewer than s of them): its sketch may need every solid hash there is.
+        if (filtered) {
             const uint64_t after = pushed_before + std::min<uint64_t>(n, (uint64_t)(tile + take) * kTileBytes);
-            const bool saturating = sk->occupied > 0 && sk->solid * 5 >= sk->occupied;
-            if (after > kUncappedBytes && !saturating) {
+            if (after > kUncappedBytes) {
                 const long double s_eff = (long double)sk->s + 8.0L * sqrtl((long double)sk->s) + 16.0L;
-                const long double t_frac = (long double)sk->last_T / (long double)sk->hash_max;
                 const long double cap_frac = 48.0L * s_eff * (long double)sk->admit_scale / (long double)after;
-                if (cap_frac < t_frac) {
+                if (cap_frac < 1.0L) {
                     const uint64_t cap = (uint64_t)(cap_frac * (long double)sk->hash_max);
-                    HIPCHK(launch_cap_threshold(sk->d_thresh, cap, g.stream)); // on the stream, in front of the tile launch
-                    sk->last_T = cap;
-                    sk->bounded = true;
+                    HIPCHK(launch_cap_threshold(sk->d_thresh, cap, sk->d_stats, g.stream)); // on the stream, in front of the tile launch
                 }
             }
         }
@@ -408,15 +400,8 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         // Sampled passes (big tables) leave the table marked dirty: finish() wants an exact one.
         HIPCHK(launch_tighten(ta, g.stream));
         if (ta.sample == 1) sk->table_dirty = false;
-        if (staged) {
-            uint64_t T;
-            rc = read_threshold(sk, &T); // sets sk->established once the pass has lowered T from solid hashes
-            if (rc) return rc;
-            sk->next_chunk_bytes = std::max<uint64_t>(sk->next_chunk_bytes, sk->bytes_pushed); // what free-running continues from
-        } else if (sk->next_chunk_bytes < (1ull << 40)) {
-            // a chunk G times everything before it admits ~G*s occurrences (times the share of erroneous k-mers
-            // under a multiplicity filter): G is what keeps that at a sixteenth (m > 1: a 64th) of the table
-            uint64_t G = sk->nslots / ((sk->m > 1 ? 64ull : 16ull) * sk->s);
+        if (!filtered && sk->next_chunk_bytes < (1ull << 40)) {
+            uint64_t G = sk->nslots / (16ull * sk->s);
             G = std::min<uint64_t>(std::max<uint64_t>(G, kChunkGrowth), 256);
             sk->next_chunk_bytes *= G;
         }
@@ -573,20 +558,23 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
 }
 
 static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
-{ // The extracted hashes are (close to) uniform below the threshold: one scatter into n buckets by value, then an
-  // insertion sort over the almost-sorted result (O(n) expected; any input still ends up sorted).
+{ // The extracted hashes are (close to) uniform below the threshold: one scatter into ~n..2n buckets by their leading
+  // bits (a shift, no division), then an insertion sort over the almost-sorted result (O(n) expected; any input still
+  // ends up sorted).
     const size_t n = keys.size();
     if (n < 2) return;
     uint64_t hi = 0;
     for (size_t i = 0; i < n; ++i) hi = keys[i] > hi ? keys[i] : hi;
-    std::vector<uint32_t> start(n + 1, 0);
-    auto bucket = [&](uint64_t k) { return (size_t)(((unsigned __int128)k * n) / ((unsigned __int128)hi + 1)); };
-    for (size_t i = 0; i < n; ++i) ++start[bucket(keys[i]) + 1];
-    for (size_t b = 0; b < n; ++b) start[b + 1] += start[b];
+    int shift = 0;
+    while ((hi >> shift) >= 2 * n) ++shift;
+    const size_t nb = (size_t)(hi >> shift) + 1;
+    std::vector<uint32_t> start(nb + 1, 0);
+    for (size_t i = 0; i < n; ++i) ++start[(size_t)(keys[i] >> shift) + 1];
+    for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
     std::vector<uint64_t> k2(n);
     std::vector<uint32_t> c2(n);
     for (size_t i = 0; i < n; ++i) {
-        const size_t d = start[bucket(keys[i])]++;
+        const size_t d = start[(size_t)(keys[i] >> shift)]++;
         k2[d] = keys[i];
         c2[d] = cnts[i];
     }
@@ -625,6 +613,8 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     const uint32_t n = (uint32_t)h[0];
     const uint64_t T = h[1], flags = h[2], maxkey = h[3];
     sk->last_T = T;
+    sk->bounded = (flags & kFlagStateBounded) != 0;
+    sk->established = (flags & kFlagStateEstablished) != 0;
     rc = check_flags(flags);
     if (rc) return rc;
     std::vector<uint64_t> keys;
@@ -696,9 +686,7 @@ extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t
     if (!sk || !d_slab || cap == 0 || (cap & 1)) return fail(MHX_E_ARG, "export_slab: null argument or odd capacity");
     uint64_t *w = (uint64_t *)d_slab;
     HIPCHK(hipMemsetAsync(w, 0, 3 * sizeof(uint64_t), g.stream));
-    // host-side state of the m > 1 phase rides in the flags word (the device flags are OR-ed in by the kernel)
-    sk->slab_state = (sk->bounded ? (uint64_t)MHX_SLAB_BOUNDED : 0) | (sk->established ? (uint64_t)MHX_SLAB_ESTABLISHED : 0);
-    if (sk->slab_state) HIPCHK(hipMemcpyAsync(w + 2, &sk->slab_state, sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    // (the extract kernel ORs the device flags and the state bits of the m > 1 phase, MHX_SLAB_*, into word [2])
     HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, w + 1, nullptr, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;

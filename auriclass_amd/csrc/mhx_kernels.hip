@@ -400,20 +400,33 @@ __global__ __launch_bounds__(256) void table_tighten_kernel(const TableArgs a)
         const uint32_t cut = cut_s;
         if (cut != 0xFFFFFFFFu && lz <= 52) {
             const uint64_t edge = (((uint64_t)cut + 1) << (53 - lz)) - 1; // last value of bin `cut`
-            if (edge < T) *a.thresh = edge;
+            if (edge < T) {
+                *a.thresh = edge;
+                if (a.min_mult > 1) a.stats[kStatEstablished] = 1; // from now on T follows the solid hashes: no more caps
+            }
         }
     }
 }
 
-// host-imposed cap of the admission threshold (multiplicity filter, before s solid hashes exist): T = min(T, cap)
-__global__ void cap_threshold_kernel(uint64_t *thresh, uint64_t cap)
+// Cap of the admission threshold that follows the bytes seen (multiplicity filter, before s solid hashes exist):
+// T = min(T, cap) -- decided on the device from what the last tighten pass left in the counters, so that the host never
+// waits for a round trip: no cap once a pass has lowered T from solid hashes, and none while the table looks like a
+// small genome sequenced deeply (a fifth of its entries solid, yet fewer than s of them: such a sketch may need every
+// solid hash there is).
+__global__ void cap_threshold_kernel(uint64_t *thresh, uint64_t cap, uint64_t *stats)
 {
-    if (*thresh > cap) *thresh = cap;
+    if (stats[kStatEstablished]) return;
+    const uint64_t occupied = stats[kStatOccupied], solid = stats[kStatSolid];
+    if (occupied > 0 && solid * 5 >= occupied) return;
+    if (*thresh > cap) {
+        *thresh = cap;
+        stats[kStatBounded] = 1;
+    }
 }
 
-hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, hipStream_t st)
+hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, uint64_t *stats, hipStream_t st)
 {
-    hipLaunchKernelGGL(cap_threshold_kernel, dim3(1), dim3(1), 0, st, thresh, cap);
+    hipLaunchKernelGGL(cap_threshold_kernel, dim3(1), dim3(1), 0, st, thresh, cap, stats);
     return hipGetLastError();
 }
 
@@ -470,7 +483,9 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     // optional: OR of the replicated device flags, so that a caller that never reads the stats block
     // (the multi-GPU slab export) still learns about a full table or a malformed FASTQ
     if (flags_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
-        const uint64_t f = a.stats[threadIdx.x * kStatCount + kStatFlags];
+        uint64_t f = a.stats[threadIdx.x * kStatCount + kStatFlags];
+        if (threadIdx.x == 0) // plus the state of the m > 1 phase
+            f |= (a.stats[kStatBounded] ? kFlagStateBounded : 0) | (a.stats[kStatEstablished] ? kFlagStateEstablished : 0);
         if (f) atomicOr(reinterpret_cast<unsigned long long *>(flags_out), (unsigned long long)f);
     }
     // Qualifying entries are sparse (about one per few hundred slots), so they are collected per
