@@ -78,7 +78,7 @@ constexpr int kDistSegs = 16;         // finish kernel: ranges are summed in 16 
 struct DistWork {
     uint32_t *offs_q;   // [nq][kDistRanges + 1] first index of every range in each query list
     uint32_t *offs_r;   // [nr][kDistRanges + 1]
-    uint16_t *cpart;    // [kDistRanges][nq][nr] shared hashes per (range, query, ref)
+    uint8_t *cpart;     // [nq][kDistRanges][4 * ceil(nr / 4)] shared hashes per (query, range, ref), one byte each
     uint32_t *params;   // [0] shift, [1] overflow flag
 };
 size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, size_t *off_c, size_t *off_p);

@@ -811,7 +811,7 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
             g.dist_ws_cap = need;
         }
         w.offs_q = (uint32_t *)(g.dist_ws + oq); w.offs_r = (uint32_t *)(g.dist_ws + orr);
-        w.cpart = (uint16_t *)(g.dist_ws + oc); w.params = (uint32_t *)(g.dist_ws + op);
+        w.cpart = g.dist_ws + oc; w.params = (uint32_t *)(g.dist_ws + op);
     }
     hipEventRecord(g.ev0, g.stream);
     hipError_t le = hipSuccess;

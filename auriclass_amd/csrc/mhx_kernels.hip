@@ -666,46 +666,57 @@ __global__ void dist_shift_kernel(const DistArgs a, DistWork w)
     }
 }
 
-__global__ void dist_split_kernel(const DistArgs a, DistWork w)
+// offs[list][p] = first element of the list whose range index (value >> shift) is >= p, for p = 0 .. kDistRanges.
+// One thread per ELEMENT: it compares its range index with its left neighbour's and writes the few offsets that fall
+// between the two (none at all for 98 % of the elements: a range holds ~49 of them).  Every list is read once, coalesced --
+// the per-offset binary searches of round 1 moved 709 MB per C5 call for 419 MB of lists and ran at the HBM limit.
+__global__ __launch_bounds__(256) void dist_split_kernel(const DistArgs a, DistWork w)
 {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t per = kDistRanges + 1;
-    if (id >= (a.nq + a.nr) * per) return;
-    const uint32_t list = id / per, p = id % per;
+    const uint32_t list = blockIdx.x, per = kDistRanges + 1; // lists along x (no 65 535 limit), element blocks along y
     const bool isq = list < a.nq;
     const uint32_t li = isq ? list : list - a.nq;
     const uint32_t n = isq ? a.q_len[li] : a.r_len[li];
     const uint64_t *v = (isq ? a.q : a.r) + (uint64_t)li * a.stride;
+    uint32_t *offs = (isq ? w.offs_q : w.offs_r) + li * per;
     const uint32_t shift = w.params[0];
-    uint32_t lo = 0, hi = n;
-    if (p == kDistRanges) lo = n;
-    else {
-        while (lo < hi) { // first element whose range index is >= p
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((v[mid] >> shift) < p) lo = mid + 1; else hi = mid;
-        }
+    // two elements per thread: one 16-byte load where the row is 16-byte aligned (8-byte loads run at 0.55-0.7x the rate)
+    const uint32_t i = 2 * (blockIdx.y * blockDim.x + threadIdx.x);
+    if (n == 0) {
+        if (blockIdx.y == 0) for (uint32_t p = threadIdx.x; p < per; p += blockDim.x) offs[p] = 0;
+        return;
     }
-    (isq ? w.offs_q : w.offs_r)[li * per + p] = lo;
+    if (i >= n) return;
+    uint64_t e0, e1 = 0;
+    const bool two = i + 1 < n;
+    if (two && (reinterpret_cast<uintptr_t>(v + i) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(v + i);
+        e0 = ((uint64_t)q.y << 32) | q.x;
+        e1 = ((uint64_t)q.w << 32) | q.z;
+    } else {
+        e0 = v[i];
+        if (two) e1 = v[i + 1];
+    }
+    const uint32_t r0 = (uint32_t)(e0 >> shift), r1 = two ? (uint32_t)(e1 >> shift) : r0;
+    // offsets p in (range of the left neighbour, range of this element] point at this element; the list's first element
+    // also serves p = 0 .. its own range, the last one leaves everything above its range at n
+    uint32_t from = i == 0 ? 0u : (uint32_t)(v[i - 1] >> shift) + 1u;
+    for (uint32_t p = from; p <= r0 && p < per; ++p) offs[p] = i;
+    if (two) for (uint32_t p = r0 + 1; p <= r1 && p < per; ++p) offs[p] = i + 1;
+    if (i + 2 >= n)
+        for (uint32_t p = r1 + 1; p < per; ++p) offs[p] = n;
 }
 
-// v_writelane_b32: lane R of `acc` := wave-uniform `value` (no clang builtin on this toolchain)
-template <int R> __device__ __forceinline__ void write_lane(uint32_t &acc, uint32_t value)
+// Sum over the wave of a word of four byte counters (no carry between the bytes as long as every total stays < 256),
+// by DPP row operations; lane 63 ends up with the totals.
+__device__ __forceinline__ uint32_t wave_sum_bytes(uint32_t v)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(value), "n"(R));
-#else
-    (void)acc; (void)value;
-#endif
-}
-// shared-hash counts of one wave-load of query elements: lane r gets the count for reference r
-template <int R> __device__ __forceinline__ void tally_refs(uint32_t &it, uint32_t m, uint32_t nr)
-{
-    if constexpr (R < 32) {
-        if (R < (int)nr) {
-            write_lane<R>(it, (uint32_t)__builtin_popcountll(__ballot(m & (1u << R))));
-            tally_refs<R + 1>(it, m, nr);
-        }
-    }
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false); // row_shr:8  -> lane 15 of every row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
 __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistWork w)
@@ -713,7 +724,9 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
     __shared__ unsigned long long keys[kDistTableSlots];
     __shared__ uint32_t masks[kDistTableSlots];
     __shared__ uint32_t too_big;
-    const uint32_t p = blockIdx.x, per = kDistRanges + 1;
+    // neighbouring ranges share the cache lines their slices begin and end in: consecutive workgroups go round the eight
+    // XCDs, so this order puts ranges p, p + 1, ... of one eighth of the value space on ONE XCD (its L2), close in time
+    const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < kDistTableSlots; i += 256) { keys[i] = kEmptyKey; masks[i] = 0; }
     if (tid == 0) {
@@ -758,10 +771,12 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
     }
     __syncthreads();
     // probe: wave w takes queries q0+w, q0+w+4, ... of this block's chunk, 8 at a time so that
-    // eight global loads are in flight per lane; each query element is looked up once and
-    // its reference mask is tallied per reference by ballot + popcount (lane r keeps ref r)
+    // eight global loads are in flight per lane; each query element is looked up once and its reference mask (one bit
+    // per reference) is spread into byte counters, four references to a word; one DPP reduction per word and query
+    // slice leaves the shared-hash counts of all references in lane 63, which stores them as bytes.
     const uint32_t qper = (a.nq + gridDim.y - 1) / gridDim.y;
     const uint32_t q0 = blockIdx.y * qper, q1 = min(a.nq, q0 + qper);
+    const uint32_t nwords = (a.nr + 3) / 4;
     constexpr int G = 8;
     for (uint32_t qb = q0 + wave; qb < q1; qb += 4 * G) {
         uint64_t x[G];
@@ -781,7 +796,11 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
         for (int g = 0; g < G; ++g) {
             const uint32_t q = qb + 4 * g;
             if (q >= q1) break;
-            uint32_t acc = 0;
+            if (ee[g] - bb[g] > 255u) { // a byte counter could overflow: not a uniform input, the generic kernel takes over
+                if (lane == 0) atomicOr(&w.params[1], 1u);
+                continue;
+            }
+            uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t i0 = bb[g]; i0 < ee[g]; i0 += 64) {
                 uint32_t m = 0;
                 if (i0 + lane < ee[g]) {
@@ -794,12 +813,17 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
                         sl = (sl + 1) & (kDistTableSlots - 1);
                     }
                 }
-                // per reference: one compare (-> SGPR mask), scalar popcount, one lane write
-                uint32_t it = 0;
-                tally_refs<0>(it, m, a.nr);
-                acc += it;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) // bits 4j .. 4j+3 of the mask -> the low bit of four bytes
+                    if (j < (int)nwords) acc[j] += (((m >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
             }
-            if (lane < (int)a.nr) w.cpart[((uint64_t)p * a.nq + q) * a.nr + lane] = (uint16_t)acc;
+            uint8_t *dst = w.cpart + ((uint64_t)q * kDistRanges + p) * (4 * nwords);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= (int)nwords) break;
+                const uint32_t tot = wave_sum_bytes(acc[j]);
+                if (lane == 63) reinterpret_cast<uint32_t *>(dst)[j] = tot;
+            }
         }
     }
 }
@@ -816,9 +840,12 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
     const bool live = pair < a.nq * a.nr;
     const uint32_t q = live ? pair / a.nr : 0, r = live ? pair % a.nr : 0, per = kDistRanges + 1;
     const uint32_t *oq = w.offs_q + q * per, *orr = w.offs_r + r * per;
+    // shared hashes per range of this pair: bytes, [query][range][4 * ceil(nr / 4)], 24 bytes apart from range to range
+    const uint32_t cstride = 4 * ((a.nr + 3) / 4);
+    const uint8_t *cp = w.cpart + (uint64_t)q * kDistRanges * cstride + r;
     {
         uint32_t com = 0;
-        for (uint32_t p = seg * RPS; p < (seg + 1) * RPS; ++p) com += w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
+        for (uint32_t p = seg * RPS; p < (seg + 1) * RPS; ++p) com += cp[(uint64_t)p * cstride];
         const uint32_t p0 = seg * RPS, p1 = (seg + 1) * RPS;
         seg_com[seg][pl] = com;
         seg_uni[seg][pl] = (orr[p1] - orr[p0]) + (oq[p1] - oq[p0]) - com;
@@ -837,7 +864,7 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
     else {
         uint32_t p = sg * RPS;
         for (;; ++p) { // the cut range is inside this segment
-            const uint32_t c = w.cpart[((uint64_t)p * a.nq + q) * a.nr + r];
+            const uint32_t c = cp[(uint64_t)p * cstride];
             const uint32_t u = (orr[p + 1] - orr[p]) + (oq[p + 1] - oq[p]) - c;
             if (uni + u >= S) break;
             uni += u;
@@ -877,7 +904,7 @@ size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, s
     size_t o = 0;
     *off_q = o; o += up((size_t)nq * (kDistRanges + 1) * 4);
     *off_r = o; o += up((size_t)nr * (kDistRanges + 1) * 4);
-    *off_c = o; o += up((size_t)kDistRanges * nq * nr * 2);
+    *off_c = o; o += up((size_t)kDistRanges * nq * 4 * ((nr + 3) / 4));
     *off_p = o; o += 256;
     return o;
 }
@@ -885,8 +912,7 @@ size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, s
 hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t st)
 {
     hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
-    const uint32_t n = (a.nq + a.nr) * (kDistRanges + 1);
-    hipLaunchKernelGGL(dist_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, w);
+    hipLaunchKernelGGL(dist_split_kernel, dim3(a.nq + a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w);
     hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
     const uint32_t pairs = a.nq * a.nr;
     hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 15) / 16), dim3(256), 0, st, a, w);
