@@ -21,6 +21,9 @@ struct HashArgs {
     uint32_t *cnts;
     uint64_t slot_mask;
     uint64_t *stats;
+    uint32_t *need_lookback; // FMT 2: set to 1 by a tile that could not find its line phase by itself (and did nothing else)
+    uint32_t repair;         // FMT 1: repair pass -- tiles that CAN find their phase by themselves only publish it
+    uint8_t *phase_rec;      // FMT 2 / repair: one phase_record() per tile of the span (0: phase unknown), for phase_verify_kernel
 };
 
 struct TableArgs {
@@ -32,6 +35,7 @@ struct TableArgs {
     uint64_t *acc;       // kAccReplicas x 8 words: accumulators of the tighten pass (occupied, solid), zero between rounds
     uint64_t *stats;
     uint32_t *done;      // ticket of the tighten pass (its last workgroup computes the new threshold), zero between rounds
+    uint32_t *need_lookback; // the sketcher's "repair pass due" word (HashArgs::need_lookback), reported by the extract kernel
     uint32_t min_mult;
     uint32_t sketch_size;
     uint32_t sample;     // tighten pass looks at one 256-slot block in `sample` (1 = exact pass)
@@ -42,6 +46,7 @@ hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st);
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st);
 hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n, hipStream_t st);
 hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, uint64_t *stats, hipStream_t st);
+hipError_t launch_phase_verify(const uint8_t *rec, uint32_t ntiles, uint64_t *stats, hipStream_t st);
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st);

@@ -27,6 +27,7 @@ constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // vacant slot of the cand
 constexpr uint64_t kFlagTableFull = 1;   // probe limit hit: result not exact, retry bigger
 constexpr uint64_t kFlagBadFastq = 2;    // a record violated the 4-line layout
 constexpr uint64_t kFlagSpinTimeout = 4; // look-back spin bound hit (should never happen)
+constexpr uint64_t kFlagNeedLookback = 8; // not an error: some FASTQ tile could not find its line phase by itself (repair pass due)
 // state bits the extract kernel adds to the flags word it reports (same values as MHX_SLAB_* of include/mhx.h)
 constexpr uint64_t kFlagStateBounded = 0x100, kFlagStateEstablished = 0x200;
 constexpr uint64_t kFlagErrorMask = 0xFF;

@@ -123,6 +123,11 @@ struct mhx_sketcher {
     uint32_t *d_tickets = nullptr; // one per tile launch since the last reset (kTicketWords of them)
     uint32_t tickets_used = 0;
     uint32_t *d_done = nullptr;    // ticket of the tighten pass
+    uint8_t *d_phase_rec = nullptr; // FASTQ: phase_record() per tile of the span being pushed (chain check)
+    uint32_t phase_rec_cap = 0;
+    uint32_t *d_need = nullptr;    // FASTQ: some tile could not find its line phase by itself -> repair pass due
+    struct Span { const void *ptr; uint64_t n; };
+    std::vector<Span> unsettled;   // FASTQ pushes whose repair question is still open (their buffers are valid until the next sync)
     uint64_t *d_tile_state = nullptr;
     size_t tile_state_cap = 0;
     uint8_t *d_stage = nullptr;
@@ -139,6 +144,8 @@ struct mhx_sketcher {
     // host
     uint64_t next_chunk_bytes = 0; // geometric schedule of the tightening phase
     uint64_t bytes_pushed = 0;
+    uint64_t repair_next_chunk_bytes = 0; // the same two for the FASTQ repair passes: the schedule the left-out tiles would
+    uint64_t repair_bytes = 0;            // have had on their own (T is at least as low as that schedule assumes)
     uint64_t expected_bytes = 0;
     uint64_t admit_scale = 1;      // multiplies the initial admission budget (retries after MHX_E_CAPACITY)
     double hash_ms = 0.0;
@@ -164,7 +171,7 @@ static TableArgs table_args(mhx_sketcher *sk)
 {
     TableArgs t;
     t.keys = sk->d_keys; t.cnts = sk->d_cnts; t.nslots = sk->nslots; t.thresh = sk->d_thresh;
-    t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.done = sk->d_done; t.min_mult = sk->m; t.sketch_size = sk->s;
+    t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.done = sk->d_done; t.need_lookback = sk->d_need; t.min_mult = sk->m; t.sketch_size = sk->s;
     t.sample = 1;
     return t;
 }
@@ -173,7 +180,7 @@ static void free_sketcher(mhx_sketcher *sk)
 {
     if (!sk) return;
     hipFree(sk->d_keys); hipFree(sk->d_cnts); hipFree(sk->d_thresh); hipFree(sk->d_hist); hipFree(sk->d_acc);
-    hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
+    hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_need); hipFree(sk->d_phase_rec); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
     hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
     hipFree(sk->d_fin);
     if (sk->h_fin) hipHostFree(sk->h_fin);
@@ -200,6 +207,7 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     HIPCHK(launch_reset(table_args(sk), sk->t_init, sk->d_tickets, kTicketWords, sk->d_out_n, g.stream));
     sk->tickets_used = 0;
     sk->table_dirty = true;
+    sk->unsettled.clear();
     sk->last_T = sk->hash_max;
     sk->bounded = false;
     sk->established = false;
@@ -211,6 +219,8 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     if (c0 > sk->nslots / 4) c0 = sk->nslots / 4; // first chunk may admit every position
     sk->next_chunk_bytes = c0;
     sk->bytes_pushed = 0;
+    sk->repair_next_chunk_bytes = c0;
+    sk->repair_bytes = 0;
     sk->hash_ms = 0.0;
     sk->launches = 0;
     return MHX_OK;
@@ -250,6 +260,7 @@ int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_byte
     A((void **)&sk->d_stats, kStatReplicas * kStatCount * sizeof(uint64_t));
     A((void **)&sk->d_tickets, kTicketWords * sizeof(uint32_t));
     A((void **)&sk->d_done, sizeof(uint32_t));
+    A((void **)&sk->d_need, sizeof(uint32_t));
     A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));
     A((void **)&sk->d_out_cnts, sk->out_cap * sizeof(uint32_t));
     A((void **)&sk->d_out_n, sizeof(uint32_t));
@@ -296,6 +307,41 @@ static int read_threshold(mhx_sketcher *sk, uint64_t *T)
     return MHX_OK;
 }
 
+// FASTQ runs in two kernel forms (mhx_kernels.hip): kernel format 2, every tile finds its line phase by itself -- no
+// ticket, no wait between workgroups --, and format 1, ticket + decoupled look-back.  A push goes through format 2; tiles
+// whose lines are too long to self-synchronise (reads beyond ~2.7 kb) leave themselves out and raise a word that
+// settle() reads at the next synchronisation point; the repair pass then runs format 1 over the same span with only
+// those tiles doing work.  (MHX_NO_SELFSYNC=1: format 1 for everything, as in round 1.)
+static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt, bool repair);
+
+static int repair_unsettled(mhx_sketcher *sk)
+{
+    std::vector<mhx_sketcher::Span> spans;
+    spans.swap(sk->unsettled);
+    HIPCHK(hipMemsetAsync(sk->d_need, 0, sizeof(uint32_t), g.stream));
+    for (const auto &sp : spans) {
+        const int rc = push_span(sk, sp.ptr, sp.n, 1, true);
+        if (rc) return rc;
+    }
+    return MHX_OK;
+}
+
+// at a synchronisation point that is not finish(): is a repair pass due for the pushes since the last one?
+static int settle(mhx_sketcher *sk)
+{
+    if (sk->unsettled.empty()) return MHX_OK;
+    uint32_t *need = reinterpret_cast<uint32_t *>(sk->h_fin); // pinned landing word
+    HIPCHK(hipMemcpyAsync(need, sk->d_need, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (*need) {
+        const int rc = repair_unsettled(sk);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    sk->unsettled.clear();
+    return MHX_OK;
+}
+
 extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int fmt)
 {
     clear_error();
@@ -304,6 +350,16 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     if (!sk || (!d_bytes && n)) return fail(MHX_E_ARG, "null argument");
     if (fmt != MHX_FMT_SEQ && fmt != MHX_FMT_FASTQ4) return fail(MHX_E_ARG, "unknown stream format %d", fmt);
     if (n == 0) return MHX_OK;
+    if (fmt == MHX_FMT_SEQ) return push_span(sk, d_bytes, n, 0, false);
+    static const bool no_selfsync = getenv("MHX_NO_SELFSYNC") != nullptr;
+    if (no_selfsync) return push_span(sk, d_bytes, n, 1, false);
+    rc = push_span(sk, d_bytes, n, 2, false);
+    if (!rc) sk->unsettled.push_back({d_bytes, n});
+    return rc;
+}
+
+static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt, bool repair)
+{
     const uintptr_t p = (uintptr_t)d_bytes;
     const uintptr_t base = p & ~(uintptr_t)15;
     HashArgs a;
@@ -314,10 +370,12 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     a.hash32 = sk->hash32 ? 1 : 0;
     a.thresh = sk->d_thresh;
     a.keys = sk->d_keys; a.cnts = sk->d_cnts; a.slot_mask = sk->nslots - 1; a.stats = sk->d_stats;
+    a.need_lookback = sk->d_need;
+    a.repair = repair ? 1u : 0u;
     const uint64_t ntiles64 = (a.end + kTileBytes - 1) / kTileBytes;
     if (ntiles64 > 0x7FFFFFFFull) return fail(MHX_E_ARG, "span too large for one push (%llu bytes)", (unsigned long long)n);
     const uint32_t ntiles = (uint32_t)ntiles64;
-    if (fmt == MHX_FMT_FASTQ4) {
+    if (kfmt == 1) {
         if (sk->tile_state_cap < ntiles) {
             HIPCHK(hipStreamSynchronize(g.stream));
             hipFree(sk->d_tile_state);
@@ -333,9 +391,23 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         }
     }
     a.tile_state = sk->d_tile_state;
+    if (kfmt == 2 || repair) { // every tile of the span writes its record: nothing to clear
+        if (sk->phase_rec_cap < ntiles) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            hipFree(sk->d_phase_rec);
+            sk->d_phase_rec = nullptr;
+            sk->phase_rec_cap = 0;
+            HIPCHK(hipMalloc((void **)&sk->d_phase_rec, (size_t)ntiles));
+            sk->phase_rec_cap = ntiles;
+        }
+    }
+    a.phase_rec = sk->d_phase_rec;
     TableArgs ta = table_args(sk);
     if (sk->nslots >= (1ull << 23) && !getenv("MHX_EXACT_TIGHTEN")) ta.sample = 8; // big tables: sampled passes between chunks (finish() counts exactly)
-    const uint64_t pushed_before = sk->bytes_pushed;
+    // a repair pass runs the same staged schedule on counters of its own (it may be the first time any k-mer is admitted)
+    uint64_t &next_chunk_bytes = repair ? sk->repair_next_chunk_bytes : sk->next_chunk_bytes;
+    uint64_t &bytes_pushed = repair ? sk->repair_bytes : sk->bytes_pushed;
+    const uint64_t pushed_before = bytes_pushed;
     uint32_t tile = 0;
     int launch = 0;
     while (tile < ntiles) {
@@ -358,12 +430,12 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         // exactness check and the retry with a 16x budget.
         const bool filtered = sk->m > 1;
         if (!last_slot) {
-            uint64_t chunk_bytes = sk->next_chunk_bytes;
+            uint64_t chunk_bytes = next_chunk_bytes;
             if (filtered) {
                 // stages are defined on the bytes actually seen (pushes may be of any size): the uncapped first MiB,
                 // then never more than x4 cumulative growth per launch
-                const uint64_t rest_of_prefix = sk->bytes_pushed < kUncappedBytes ? kUncappedBytes - sk->bytes_pushed : 0;
-                chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * sk->bytes_pushed);
+                const uint64_t rest_of_prefix = bytes_pushed < kUncappedBytes ? kUncappedBytes - bytes_pushed : 0;
+                chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * bytes_pushed);
             }
             const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
             if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
@@ -383,7 +455,7 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         a.ntiles = take;
         a.ticket = sk->d_tickets + sk->tickets_used++;
         if (g.profiling) HIPCHK(hipEventRecord(g.ev0, g.stream));
-        HIPCHK(launch_hash(sk->k, fmt, a, g.stream));
+        HIPCHK(launch_hash(sk->k, kfmt, a, g.stream));
         if (g.profiling) {
             HIPCHK(hipEventRecord(g.ev1, g.stream));
             HIPCHK(hipEventSynchronize(g.ev1));
@@ -395,17 +467,18 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
         ++launch;
         tile += take;
         sk->table_dirty = true;
-        sk->bytes_pushed = pushed_before + std::min<uint64_t>(n, (uint64_t)tile * kTileBytes); // real bytes, not whole tiles: callers may push tiny spans
+        bytes_pushed = pushed_before + std::min<uint64_t>(n, (uint64_t)tile * kTileBytes); // real bytes, not whole tiles: callers may push tiny spans
         // tighten T from what has been seen (also after the last launch of a push: the next push starts from it).
         // Sampled passes (big tables) leave the table marked dirty: finish() wants an exact one.
         HIPCHK(launch_tighten(ta, g.stream));
         if (ta.sample == 1) sk->table_dirty = false;
-        if (!filtered && sk->next_chunk_bytes < (1ull << 40)) {
+        if (!filtered && next_chunk_bytes < (1ull << 40)) {
             uint64_t G = sk->nslots / (16ull * sk->s);
             G = std::min<uint64_t>(std::max<uint64_t>(G, kChunkGrowth), 256);
-            sk->next_chunk_bytes *= G;
+            next_chunk_bytes *= G;
         }
     }
+    if (kfmt == 2 || repair) HIPCHK(launch_phase_verify(sk->d_phase_rec, ntiles, sk->d_stats, g.stream));
     return MHX_OK;
 }
 
@@ -416,7 +489,9 @@ extern "C" int mhx_sketcher_push_host(mhx_sketcher *sk, const void *h_bytes, uin
     if (rc) return rc;
     if (!sk || (!h_bytes && n)) return fail(MHX_E_ARG, "null argument");
     if (n == 0) return MHX_OK;
-    // the staging buffer is reused: wait for earlier pushes that may still read it
+    // the staging buffer is reused: earlier pushes that may still read it (or need it for a repair pass) come first
+    rc = settle(sk);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     if (sk->stage_cap < n + 64) {
         hipFree(sk->d_stage);
@@ -435,7 +510,10 @@ extern "C" int mhx_sketcher_sync(mhx_sketcher *sk)
     clear_error();
     int rc = require_engine();
     if (rc) return rc;
-    (void)sk;
+    if (sk) {
+        rc = settle(sk); // a repair pass, if one is due, runs while the pushed buffers are still the caller's to keep
+        if (rc) return rc;
+    }
     HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
 }
@@ -465,6 +543,8 @@ extern "C" int mhx_sketcher_stats(mhx_sketcher *sk, uint64_t *stats8)
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !stats8) return fail(MHX_E_ARG, "null argument");
+    rc = settle(sk);
+    if (rc) return rc;
     uint64_t s[kStatCount];
     rc = fetch_stats(sk, s);
     if (rc) return rc;
@@ -487,6 +567,8 @@ extern "C" int mhx_sketcher_record_count(mhx_sketcher *sk, uint64_t *records)
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !records) return fail(MHX_E_ARG, "null argument");
+    rc = settle(sk);
+    if (rc) return rc;
     uint64_t s[kStatCount];
     rc = fetch_stats(sk, s);
     if (rc) return rc;
@@ -516,6 +598,8 @@ extern "C" int mhx_sketcher_threshold(mhx_sketcher *sk, uint64_t *threshold)
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !threshold) return fail(MHX_E_ARG, "null argument");
+    rc = settle(sk);
+    if (rc) return rc;
     HIPCHK(launch_tighten(table_args(sk), g.stream));
     return read_threshold(sk, threshold);
 }
@@ -601,6 +685,7 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     const uint32_t cap = sk->fin_cap;
     uint64_t *d = sk->d_fin;
     const size_t fin_bytes = (4 + (size_t)cap + cap / 2) * sizeof(uint64_t);
+  again:
     if (sk->table_dirty) {
         HIPCHK(launch_tighten(table_args(sk), g.stream));
         sk->table_dirty = false;
@@ -612,6 +697,12 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     const uint64_t *h = sk->h_fin;
     const uint32_t n = (uint32_t)h[0];
     const uint64_t T = h[1], flags = h[2], maxkey = h[3];
+    if ((flags & kFlagNeedLookback) && !sk->unsettled.empty()) { // FASTQ tiles left out by the self-synchronising pass
+        rc = repair_unsettled(sk);
+        if (rc) return rc;
+        goto again;
+    }
+    sk->unsettled.clear();
     sk->last_T = T;
     sk->bounded = (flags & kFlagStateBounded) != 0;
     sk->established = (flags & kFlagStateEstablished) != 0;
@@ -651,6 +742,8 @@ static int mhx_sketcher_export_impl(mhx_sketcher *sk, uint64_t limit, uint64_t *
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !n_out) return fail(MHX_E_ARG, "null argument");
+    rc = settle(sk);
+    if (rc) return rc;
     uint64_t st[kStatCount];
     rc = fetch_stats(sk, st);
     if (rc) return rc;
@@ -684,6 +777,8 @@ extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t
     int rc = require_engine();
     if (rc) return rc;
     if (!sk || !d_slab || cap == 0 || (cap & 1)) return fail(MHX_E_ARG, "export_slab: null argument or odd capacity");
+    rc = settle(sk);
+    if (rc) return rc;
     uint64_t *w = (uint64_t *)d_slab;
     HIPCHK(hipMemsetAsync(w, 0, 3 * sizeof(uint64_t), g.stream));
     // (the extract kernel ORs the device flags and the state bits of the m > 1 phase, MHX_SLAB_*, into word [2])

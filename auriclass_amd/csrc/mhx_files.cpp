@@ -639,7 +639,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
             if (c.first_of_file) header.offer(c.file, c.data(), std::min<size_t>(c.size, 1u << 20), k);
             if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
             rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
-            if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MHX_E_HIP, "stream sync failed");
+            if (!rc) rc = mhx_sketcher_sync(sk); // the slot is overwritten next: the push (and a repair pass, if due) must be through
             if (rc) q.abort();
             else q.give_back(std::move(c.buf)); // the copy out of it has completed
         }

@@ -1,9 +1,12 @@
 // mhx_kernels.hip -- gfx950 kernels of the sketch + distance engine.
 //
 //   sketch_tile_kernel<K,FMT>  one workgroup per 16 KiB tile of the FASTQ / sequence byte
-//                              stream: stage -> classify -> (FASTQ) decoupled look-back for
-//                              the line phase -> valid k-mer starts -> LDS work list ->
-//                              canonical k-mer + MurmurHash3_x64_128 -> admission -> table
+//                              stream: stage -> classify -> (FASTQ) line phase -> candidate k-mer
+//                              starts -> LDS work list -> canonical k-mer + MurmurHash3_x64_128 ->
+//                              admission -> table.  FMT 0: sequence stream; FMT 2: FASTQ, every tile
+//                              finds its line phase by itself (no ticket, no inter-workgroup wait);
+//                              FMT 1: FASTQ with ticket + decoupled look-back, the repair pass for the
+//                              tiles FMT 2 had to leave out (lines too long to self-synchronise)
 //   table_tighten              tightens the admission threshold T from the candidate table (one launch)
 //   table_reset                vacates the table and clears the control buffers (one launch)
 //   table_extract              compact (hash,count) entries <= limit for the host / all-gather
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t value, uint32_t *wa
 template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) void sketch_tile_kernel(const HashArgs a)
 {
     __shared__ TileSmem sm;
-    constexpr bool FASTQ = (FMT == 1);
+    constexpr bool FASTQ = (FMT != 0), LOOKBACK = (FMT == 1), SELFSYNC = (FMT == 2);
     const int tid = threadIdx.x;
     // the parsing phases are latency-bound (loads, barriers, look-back): at high priority their few instructions do
     // not queue behind the hash loops of the other resident workgroups, so a wave reaches its own hash loop sooner
@@ -166,7 +169,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
 
     // tile id: in ticket order for FASTQ (look-back needs started-before ordering)
     uint32_t tile;
-    if (FASTQ) {
+    if (LOOKBACK) {
         if (tid == 0) sm.misc[2] = a.tile0 + atomicAdd(a.ticket, 1u);
         __syncthreads();
         tile = sm.misc[2];
@@ -202,20 +205,41 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
 
     MHX_STAMP(); // 1: classify
     uint32_t line_base = 0, excl = 0, tile_total = 0;
-    if (FASTQ) {
-        excl = block_scan_excl(st.nlcount, sm.cnt, tile_total);
-        if (tid < 64) {
-            const uint32_t lb = lookback_wave(a.tile_state, tile, a.first_tile, tile_total, stats);
-            if (tid == 0) sm.misc[0] = lb;
-        }
-        __syncthreads();
-        line_base = sm.misc[0];
-    }
-    MHX_STAMP(); // 2: newline scan + look-back
-    bool bad = false;
     // the format look-ahead may only read staged bytes that belong to the span
     const uint64_t span_left = a.end > tile_off ? a.end - tile_off : 0;
     const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
+    if (FASTQ) {
+        excl = block_scan_excl(st.nlcount, sm.cnt, tile_total); // barrier inside: the newline map is complete
+        // the tile that holds the start of the span begins a record there; every other tile looks at its own first lines
+        if (tid == 0) sm.misc[0] = tile == a.first_tile ? 0u : phase_selfsync(sm, check_limit);
+        __syncthreads();
+        const uint32_t self_phase = sm.misc[0];
+        if (SELFSYNC) {
+            if (self_phase == 4u) { // lines too long to tell: left to the look-back pass, nothing of this tile is counted now
+                if (tid == 0) { a.phase_rec[tile - a.first_tile] = 0; atomicOr(a.need_lookback, 1u); }
+                return;
+            }
+            if (tid == 0) a.phase_rec[tile - a.first_tile] = phase_record(self_phase, tile_total);
+            line_base = self_phase;
+        } else {
+            if (a.repair && self_phase != 4u) { // repair pass: this tile was done in the first pass, it only publishes its phase
+                if (tid == 0) {
+                    st_state(&a.tile_state[tile], (2ull << 32) | (uint64_t)(self_phase + tile_total));
+                    a.phase_rec[tile - a.first_tile] = phase_record(self_phase, tile_total);
+                }
+                return;
+            }
+            if (tid < 64) {
+                const uint32_t lb = lookback_wave(a.tile_state, tile, a.first_tile, tile_total, stats);
+                if (tid == 0) sm.misc[0] = lb;
+            }
+            __syncthreads();
+            line_base = sm.misc[0];
+            if (a.repair && tid == 0) a.phase_rec[tile - a.first_tile] = phase_record(line_base, tile_total);
+        }
+    }
+    MHX_STAMP(); // 2: newline scan + look-back
+    bool bad = false;
     const uint32_t long_records = phase_good<FASTQ>(sm, tid, st, line_base, excl, tile_total, check_limit, bad, tile_off, a.end, (uint32_t)K);
     if (FASTQ && bad) atomicOr(&stats[kStatFlags], (unsigned long long)kFlagBadFastq);
     if (FASTQ && long_records) atomicAdd(&sm.misc[5], long_records);
@@ -251,6 +275,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
 template <int K> static hipError_t launch_k(int fmt, const HashArgs &a, hipStream_t st)
 {
     if (fmt == 1) hipLaunchKernelGGL((sketch_tile_kernel<K, 1>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
+    else if (fmt == 2) hipLaunchKernelGGL((sketch_tile_kernel<K, 2>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL((sketch_tile_kernel<K, 0>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
@@ -424,6 +449,21 @@ __global__ void cap_threshold_kernel(uint64_t *thresh, uint64_t cap, uint64_t *s
     }
 }
 
+// FASTQ, self-synchronising form: do the line phases the tiles found (HashArgs::phase_rec) form one chain?
+__global__ void phase_verify_kernel(const uint8_t *rec, uint32_t ntiles, uint64_t *stats)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u;
+    if (i < ntiles && phase_chain_broken(rec[i - 1], rec[i]))
+        atomicOr(reinterpret_cast<unsigned long long *>(stats) + kStatFlags, (unsigned long long)kFlagBadFastq);
+}
+
+hipError_t launch_phase_verify(const uint8_t *rec, uint32_t ntiles, uint64_t *stats, hipStream_t st)
+{
+    if (ntiles < 2) return hipSuccess;
+    hipLaunchKernelGGL(phase_verify_kernel, dim3((ntiles - 1 + 255) / 256), dim3(256), 0, st, rec, ntiles, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, uint64_t *stats, hipStream_t st)
 {
     hipLaunchKernelGGL(cap_threshold_kernel, dim3(1), dim3(1), 0, st, thresh, cap, stats);
@@ -455,7 +495,7 @@ __global__ __launch_bounds__(256) void table_reset_kernel(const TableArgs a, uin
         for (uint32_t i = threadIdx.x; i < (uint32_t)kAccReplicas * 8; i += blockDim.x) a.acc[i] = 0;
         for (uint32_t i = threadIdx.x; i < (uint32_t)(kStatReplicas * kStatCount); i += blockDim.x) a.stats[i] = 0;
         for (uint32_t i = threadIdx.x; i < ntickets; i += blockDim.x) tickets[i] = 0;
-        if (threadIdx.x == 0) { *a.thresh = t_init; *a.done = 0; *out_n = 0; }
+        if (threadIdx.x == 0) { *a.thresh = t_init; *a.done = 0; *out_n = 0; if (a.need_lookback) *a.need_lookback = 0; }
     }
 }
 
@@ -484,8 +524,9 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     // (the multi-GPU slab export) still learns about a full table or a malformed FASTQ
     if (flags_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
         uint64_t f = a.stats[threadIdx.x * kStatCount + kStatFlags];
-        if (threadIdx.x == 0) // plus the state of the m > 1 phase
-            f |= (a.stats[kStatBounded] ? kFlagStateBounded : 0) | (a.stats[kStatEstablished] ? kFlagStateEstablished : 0);
+        if (threadIdx.x == 0) // plus the state of the m > 1 phase and the "repair pass due" word of the FASTQ parser
+            f |= (a.stats[kStatBounded] ? kFlagStateBounded : 0) | (a.stats[kStatEstablished] ? kFlagStateEstablished : 0) |
+                 (a.need_lookback && *a.need_lookback ? kFlagNeedLookback : 0);
         if (f) atomicOr(reinterpret_cast<unsigned long long *>(flags_out), (unsigned long long)f);
     }
     // Qualifying entries are sparse (about one per few hundred slots), so they are collected per

@@ -386,6 +386,48 @@ MHX_HD void phase_classify(TileSmem &sm, int tid, ThreadState &st, uint64_t tile
 }
 
 
+// FASTQ line phase of a tile WITHOUT its predecessors: the line index (mod 4) of the tile's first byte, or 4 if the tile
+// cannot tell.  A header is the only line that starts with '@', is followed by a line that does not, and then by a line
+// that starts with '+' (a quality line may start with '@', but the line after it is a header and starts with '@' too), so
+// the first such triple among the tile's first six line starts fixes the phase: with i newlines in front of the header
+// line the tile's first byte lies in line -i (mod 4).  Needs six newlines within the staged, in-span bytes -- reads of up
+// to ~2.7 kb; tiles of longer lines take the look-back pass instead.  The per-record layout check of phase_good still
+// runs over every line, so a phase derived from a malformed file is caught there.
+MHX_HD uint32_t phase_selfsync(TileSmem &sm, uint32_t check_limit)
+{
+    const uint32_t *nlmap = tile_nlmap(sm);
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(sm.bytes);
+    uint32_t pos[6];
+    int n = 0;
+    for (int w = 0; w < kTileBytes / 32 + 2 && n < 6; ++w) {
+        uint32_t m = nlmap[w];
+        while (m && n < 6) {
+            pos[n++] = 32u * (uint32_t)w + (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+        }
+    }
+    for (int i = 0; i + 2 < n && i < 4; ++i) {
+        const uint32_t p0 = pos[i] + 1u, p1 = pos[i + 1] + 1u, p2 = pos[i + 2] + 1u;
+        if (p2 >= check_limit) break;
+        if (b[p0] == '@' && b[p1] != '@' && b[p1] != '+' && b[p2] == '+') return (4u - ((uint32_t)(i + 1) & 3u)) & 3u;
+    }
+    return 4u;
+}
+
+// What a tile leaves behind for the chain check: the line phase of its first byte and of the first byte of the next
+// tile.  phase_verify_kernel compares neighbours, so that the phases the tiles found by themselves are the ones a
+// running line count from the start of the span gives -- a file on which they are not (a record cut short in front of
+// a tile border, which kseq reads as a record without qualities) is flagged and goes to the general parser.
+constexpr uint8_t kPhaseKnown = 0x10;
+MHX_HD uint8_t phase_record(uint32_t start_phase, uint32_t tile_lines)
+{
+    return (uint8_t)(kPhaseKnown | (start_phase & 3u) | (((start_phase + tile_lines) & 3u) << 2));
+}
+MHX_HD bool phase_chain_broken(uint8_t prev, uint8_t cur)
+{
+    return (prev & kPhaseKnown) && (cur & kPhaseKnown) && ((prev >> 2) & 3u) != (cur & 3u);
+}
+
 // P2c: bytes a k-mer may cover -> good map: FASTQ: the bytes of sequence lines; sequence stream: everything but the
 // record separators.  (Whether they are A/C/G/T is checked for the few windows that pass the threshold.)
 // returns the number of records of this thread's bytes whose sequence line holds >= k bytes

@@ -25,6 +25,7 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
     const uint32_t first_tile = (uint32_t)(begin / kTileBytes);
     const uint32_t ntiles = (uint32_t)((end + kTileBytes - 1) / kTileBytes);
     uint32_t line_prefix = 0;
+    uint8_t prev_rec = 0;
     VecInserter ins{&out};
     for (uint32_t tile = first_tile; tile < ntiles; ++tile) {
         const uint64_t tile_off = (uint64_t)tile * kTileBytes;
@@ -40,6 +41,15 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         bool bad = false;
         const uint64_t span_left = end > tile_off ? end - tile_off : 0;
         const uint32_t check_limit = span_left < (uint64_t)(kTileBytes + kHaloBytes) ? (uint32_t)span_left : (uint32_t)(kTileBytes + kHaloBytes);
+        if (FASTQ) { // the self-synchronising form of the kernel: the phase a tile finds by itself, and the chain check
+            const uint32_t self = tile == first_tile ? 0u : phase_selfsync(sm, check_limit);
+            if (self == 4u) ++stats[6];                          // tiles left to the look-back pass
+            else if (self != (line_base & 3u)) stats[5] |= 1u;   // a phase that is not the running line count's
+            // after the repair pass every tile has a record; the tiles that needed it carry the look-back's phase
+            const uint8_t rec = phase_record(self == 4u ? line_base : self, tile_total);
+            if (tile != first_tile && phase_chain_broken(prev_rec, rec)) stats[5] |= 2u; // what phase_verify_kernel flags
+            prev_rec = rec;
+        }
         for (int t = 0; t < kBlock; ++t) stats[kStatRecords] += phase_good<FASTQ>(sm, t, st[t], line_base, excl[t], tile_total, check_limit, bad, tile_off, end, (uint32_t)K);
         if (bad) stats[kStatFlags] |= kFlagBadFastq;
         uint32_t ex2[kBlock], run = 0;

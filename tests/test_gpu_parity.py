@@ -990,3 +990,94 @@ def test_multi_member_gz_and_wrong_crc_through_the_ingest(tmp_path):
     q.write_bytes(bytes(bad))
     with pytest.raises(engine.EngineError):
         engine.sketch_files([q], 21, 2000, tmp_path / "x.msh", reads=True, min_mult=2)
+
+
+def _long_read_fastq(rng, genome: bytes, n, lo, hi):
+    reads, rec = [], []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        o = int(rng.integers(0, len(genome) - L))
+        r = genome[o:o + L]
+        reads.append(r)
+        q = bytes(rng.choice(np.frombuffer(b"@+5I#", np.uint8), size=L))
+        rec.append(b"@ont%d ch=%d\n" % (i, i % 512) + r + b"\n+\n" + q + b"\n")
+    return reads, b"".join(rec)
+
+
+@pytest.mark.parametrize("lo,hi,m", [(3_000, 60_000, 1), (100, 9_000, 2), (2_000, 3_500, 1)])
+def test_long_read_fastq_takes_the_look_back_repair_pass(lo, hi, m):
+    """Reads beyond ~2.7 kb: a 32 KiB tile sees fewer than six line starts and cannot find its line phase by itself;
+    such tiles are left out of the first pass and sketched by the look-back pass that settle()/finish() start.  Pushes
+    from device memory (finish() repairs) and through the host staging buffer (the next push repairs)."""
+    import torch
+
+    rng = np.random.default_rng(lo + hi)
+    genome = synth.make_genome(400_000, seed=31).tobytes()
+    reads, data = _long_read_fastq(rng, genome, 400, lo, hi)
+    ref, (want, want_c) = oracle_sketch(data, 21, 2000, m)
+    dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    sk = engine.Sketcher(21, 2000, m, expected_bytes=2 * len(data))
+    sk.push_device(dev.data_ptr(), len(data), engine.FMT_FASTQ4)
+    got, cnt = sk.finish()
+    st = sk.stats()
+    assert np.array_equal(got, want) and np.all(cnt >= want_c)   # exact multiplicities; mash's heap forgets evicted ones
+    assert st["lines"] == 4 * len(reads) and st["flags"] == 0 and sk.record_count() == ref.records
+    # two host pushes, halves cut at a record border: the first is repaired before the staging buffer is reused
+    cut = data.index(b"\n@ont200 ") + 1
+    sk.reset()
+    sk.push_host(data[:cut], engine.FMT_FASTQ4)
+    sk.push_host(data[cut:], engine.FMT_FASTQ4)
+    again, cnt2 = sk.finish()
+    st2 = sk.stats()
+    sk.close()
+    assert np.array_equal(again, want) and np.array_equal(cnt2, cnt)
+    assert st2["lines"] == 4 * len(reads) and st2["kmers"] == st["kmers"]
+
+
+def test_long_read_fastq_gz_through_the_chunked_ingest(tmp_path, monkeypatch):
+    """The streaming ingest reuses its device slots: the repair pass of a chunk has to run before the slot is refilled."""
+    import gzip
+
+    rng = np.random.default_rng(8)
+    genome = synth.make_genome(300_000, seed=32).tobytes()
+    reads, data = _long_read_fastq(rng, genome, 2500, 500, 40_000)   # ~100 MB: four 32 MiB chunks
+    p = tmp_path / "ont.fastq.gz"
+    p.write_bytes(gzip.compress(data, 1))
+    engine.sketch_files([p], 27, 5000, tmp_path / "o.msh", reads=True, min_mult=1)
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    ref, (want, _) = oracle_sketch(data, 27, 5000, 1)
+    assert np.array_equal(got.hashes, want)
+    assert got.comment == ref.comment()
+
+
+def test_record_without_qualities_in_front_of_a_tile_border(tmp_path):
+    """'@h / SEQ / @h2 ...': kseq reads a record without qualities.  When the cut record's sequence line straddles a tile
+    border, every tile's own first lines look regular; the chain check over the tiles' phases refuses the 4-line path
+    (MHX_E_FORMAT on a raw push) and the file-level call sketches the file with the general record parser."""
+    rng = np.random.default_rng(77)
+    reads = random_reads(rng, 600, 100, 150, p_n=0, p_lower=0)
+    recs = [b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads)]
+    body, i = b"", 0
+    while len(body) < 32768 - 900:
+        body += recs[i]
+        i += 1
+    L = (32768 - 100 - len(body) - 7) // 2
+    filler = b"C" * L
+    body += b"@f\n" + filler + b"\n+\n" + b"I" * L + b"\n"
+    cut_seq = b"ACGGTCA" * 34
+    data = body + b"@cut\n" + cut_seq + b"\n" + b"".join(recs[i:])
+    assert len(body) + 5 < 32768 < len(body) + 5 + len(cut_seq)
+    import torch
+    dev = torch.frombuffer(bytearray(data + b"\0" * 64), dtype=torch.uint8).cuda()   # 16-byte aligned: tile borders as computed
+    sk = engine.Sketcher(21, 1000, 1, expected_bytes=len(data))
+    sk.push_device(dev.data_ptr(), len(data), engine.FMT_FASTQ4)
+    with pytest.raises(engine.EngineError) as e:
+        sk.finish()
+    assert e.value.code == engine.MHX_E_FORMAT
+    sk.close()
+    p = tmp_path / "cut.fq"
+    p.write_bytes(data)
+    engine.sketch_files([p], 21, 1000, tmp_path / "c.msh", reads=True, min_mult=1)
+    got = mo.read_msh(tmp_path / "c.msh").references[0].hashes
+    want, _ = mo.bruteforce_sketch(reads[:i] + [filler, cut_seq] + reads[i:], 21, 1000, 1)
+    assert np.array_equal(got, want)

@@ -103,6 +103,8 @@ def test_fastq4_stream(emul, k, lead):
     got, stats = run_emul(emul, data, k, fmt=1, lead=lead)
     want = oracle_hashes(reads, k)
     assert int(stats[3]) == 0, "format flag raised on a valid FASTQ"
+    assert int(stats[5]) == 0, "a tile found a line phase that is not the running line count's"
+    assert int(stats[6]) == 0, "short reads: every tile finds its phase by itself"
     assert int(stats[2]) == 4 * len(reads)
     assert stats[0] == sum(max(0, len(r) - k + 1) for r in reads) >= len(want)
     assert np.array_equal(got, want)
@@ -115,6 +117,46 @@ def test_fastq4_no_trailing_newline_and_long_lines(emul):
     got, stats = run_emul(emul, data, 21, fmt=1, lead=3)
     assert np.array_equal(got, oracle_hashes(reads, 21))
     assert int(stats[3]) == 0
+    assert int(stats[5]) == 0 and int(stats[6]) > 0   # such tiles are left to the look-back (repair) pass
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_selfsync_phase_is_the_running_line_count(emul, seed):
+    """Quality lines that begin with '@' or '+', empty reads, reads of 1..3000 bases: whenever a tile names a phase it
+    is the true one, and the chain check has nothing to flag."""
+    rng = np.random.default_rng(900 + seed)
+    hi = [40, 300, 3000, 3000, 9000, 120][seed]
+    reads = random_reads(rng, 400 if hi > 1000 else 3000, 0, hi)
+    out = []
+    for i, r in enumerate(reads):
+        q = bytearray(rng.choice(np.frombuffer(b"@+I#", np.uint8), size=len(r)).tobytes())
+        if q and rng.random() < 0.5:
+            q[0] = ord("@") if rng.random() < 0.5 else ord("+")
+        out.append(b"@%d\n" % i + r + b"\n+" + (b"@x" if rng.random() < 0.3 else b"") + b"\n" + bytes(q) + b"\n")
+    data = b"".join(out)
+    got, stats = run_emul(emul, data, 21, fmt=1, lead=int(rng.integers(0, 70000)))
+    assert int(stats[3]) == 0 and int(stats[5]) == 0
+    assert np.array_equal(got, oracle_hashes(reads, 21))
+
+
+def test_record_cut_short_in_front_of_a_tile_border_breaks_the_chain(emul):
+    """kseq reads '@h\\nSEQ\\n@h2...' as a record without qualities; the 4-line fast path must refuse it even when the
+    cut falls so that every tile's own first lines look regular."""
+    rng = np.random.default_rng(77)
+    reads = random_reads(rng, 600, 100, 150, p_n=0, p_lower=0)
+    recs = [b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads)]
+    body, i = b"", 0
+    while len(body) < 32768 - 900:
+        body += recs[i]
+        i += 1
+    gap = 32768 - 100 - len(body)            # the cut record's header starts ~100 bytes in front of the border
+    L = (gap - 7) // 2
+    body += b"@f\n" + b"C" * L + b"\n+\n" + b"I" * L + b"\n"
+    data = body + b"@cut\n" + b"ACGT" * 60 + b"\n" + b"".join(recs[i:])
+    assert len(body) + 5 < 32768 < len(body) + 5 + 240
+    _, stats = run_emul(emul, data, 21, fmt=1)
+    assert int(stats[5]) & 1, "the tile after the border takes the rest of the cut line for a quality line"
+    assert (int(stats[3]) & 2) or (int(stats[5]) & 2)
 
 
 def test_fastq_layout_violation_is_flagged(emul):
