@@ -39,6 +39,7 @@ struct TableArgs {
     uint32_t min_mult;
     uint32_t sketch_size;
     uint32_t sample;     // tighten pass looks at one 256-slot block in `sample` (1 = exact pass)
+    uint64_t next_cap;   // tighten pass, m > 1: byte-count cap to apply behind the new threshold (0: none), see cap_threshold_kernel
 };
 
 // launchers (mhx_kernels.hip)
@@ -46,10 +47,12 @@ hipError_t launch_hash(int k, int fmt, const HashArgs &a, hipStream_t st);
 hipError_t launch_tighten(const TableArgs &a, hipStream_t st);
 hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, uint32_t ntickets, uint32_t *out_n, hipStream_t st);
 hipError_t launch_cap_threshold(uint64_t *thresh, uint64_t cap, uint64_t *stats, hipStream_t st);
+hipError_t launch_order_block(const uint64_t *blk, uint32_t cap, uint32_t log2_buckets, uint32_t *cursor, uint32_t *starts,
+                              uint32_t *group_total, uint64_t *grouped, uint64_t *host_blk, hipStream_t st);
 hipError_t launch_phase_verify(const uint8_t *rec, uint32_t ntiles, uint64_t *stats, hipStream_t st);
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
-                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st);
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor = nullptr, uint32_t order_log2 = 0);
 bool hash_k_supported(int k);
 
 // FASTA on the device (mhx_fasta.hip): raw file bytes -> dense sequence stream + record separator positions.

@@ -11,6 +11,7 @@
 
 
 #include <algorithm>
+#include <chrono>
 #include <exception>
 #include <new>
 #include <memory>
@@ -106,7 +107,16 @@ extern "C" int mhx_set_profiling(int on)
 }
 
 // ---- sketcher -------------------------------------------------------------------------
+constexpr uint32_t kDeviceOrderMinSketch = 8192;
+
+struct SortScratch {
+    std::vector<uint32_t> start;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> cnts;
+};
+
 struct mhx_sketcher {
+    SortScratch sorted;            // finish() / export(): the extracted entries in hash order
     int k = 0;
     uint32_t s = 0, m = 1;
     bool hash32 = false;
@@ -140,7 +150,12 @@ struct mhx_sketcher {
     // mirror, so the result comes back in ONE copy (five separate copies cost 20-60 us of idle gap each)
     uint64_t *d_fin = nullptr, *h_fin = nullptr;
     uint32_t fin_cap = 0;
-    bool table_dirty = true;   // tiles have been hashed since the last tighten pass
+    // large sketches: a second block, the first in (almost) hash order (launch_order_block), and its bucket counters
+    uint64_t *d_fin_ordered = nullptr;
+    uint32_t *d_order_buckets = nullptr, *d_order_starts = nullptr, *d_order_groups = nullptr;
+    uint32_t order_log2 = 0;
+    bool table_dirty = true;   // tiles have been hashed since the last EXACT tighten pass
+    bool table_sampled = false; // ... but a sampled pass has run after the last of them: T is valid and ~s' solid hashes lie below it
     // host
     uint64_t next_chunk_bytes = 0; // geometric schedule of the tightening phase
     uint64_t bytes_pushed = 0;
@@ -173,6 +188,7 @@ static TableArgs table_args(mhx_sketcher *sk)
     t.keys = sk->d_keys; t.cnts = sk->d_cnts; t.nslots = sk->nslots; t.thresh = sk->d_thresh;
     t.hist = sk->d_hist; t.acc = sk->d_acc; t.stats = sk->d_stats; t.done = sk->d_done; t.need_lookback = sk->d_need; t.min_mult = sk->m; t.sketch_size = sk->s;
     t.sample = 1;
+    t.next_cap = 0;
     return t;
 }
 
@@ -183,6 +199,10 @@ static void free_sketcher(mhx_sketcher *sk)
     hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_need); hipFree(sk->d_phase_rec); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
     hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
     hipFree(sk->d_fin);
+    hipFree(sk->d_fin_ordered);
+    hipFree(sk->d_order_buckets);
+    hipFree(sk->d_order_starts);
+    hipFree(sk->d_order_groups);
     if (sk->h_fin) hipHostFree(sk->h_fin);
     delete sk;
 }
@@ -264,9 +284,19 @@ int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_byte
     A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));
     A((void **)&sk->d_out_cnts, sk->out_cap * sizeof(uint32_t));
     A((void **)&sk->d_out_n, sizeof(uint32_t));
-    sk->fin_cap = (2 * s + 4096 + 1) & ~1u;
+    sk->fin_cap = (s + 16u * (uint32_t)sqrt((double)s) + 4096u + 1u) & ~1u; // what a sampled threshold leaves, with room (finish())
     const size_t fin_bytes = (4 + (size_t)sk->fin_cap + sk->fin_cap / 2) * sizeof(uint64_t);
     A((void **)&sk->d_fin, fin_bytes);
+    if (s >= kDeviceOrderMinSketch) { // below that the host's bucket sort costs less than three more launches
+        sk->order_log2 = 12;
+        while ((1u << sk->order_log2) < sk->fin_cap && sk->order_log2 < 20) ++sk->order_log2;
+        A((void **)&sk->d_fin_ordered, fin_bytes);
+        A((void **)&sk->d_order_buckets, ((size_t)1 << sk->order_log2) * sizeof(uint32_t));
+        A((void **)&sk->d_order_starts, (((size_t)1 << sk->order_log2) + 4) * sizeof(uint32_t));
+        A((void **)&sk->d_order_groups, 1024 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(sk->d_order_starts, 0, (((size_t)1 << sk->order_log2) + 4) * sizeof(uint32_t)); // [nbuckets] stays zero
+        if (e == hipSuccess) e = hipMemset(sk->d_order_buckets, 0, ((size_t)1 << sk->order_log2) * sizeof(uint32_t)); // every finish() leaves them zero again
+    }
     if (e == hipSuccess) e = hipHostMalloc((void **)&sk->h_fin, fin_bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         free_sketcher(sk);
@@ -408,28 +438,27 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
     uint64_t &next_chunk_bytes = repair ? sk->repair_next_chunk_bytes : sk->next_chunk_bytes;
     uint64_t &bytes_pushed = repair ? sk->repair_bytes : sk->bytes_pushed;
     const uint64_t pushed_before = bytes_pushed;
-    uint32_t tile = 0;
-    int launch = 0;
-    while (tile < ntiles) {
-        uint32_t take = ntiles - tile;
-        const bool last_slot = launch == kMaxLaunchesPerPush - 1;
-        // The host never looks at T while pushing: every launch is followed by a tighten pass on the stream and nothing
-        // waits for a round trip.
-        // No multiplicity filter: launches grow by a factor G.  After a chunk of N k-mers T sits at the s-th smallest of
-        // them, hence the next, G times larger chunk admits ~G*s occurrences: G is what keeps that at a sixteenth of the
-        // table whatever the input is.
-        // Multiplicity filter (m > 1): T cannot follow the data before s hashes with count >= m exist, and until then
-        // every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is admitted whole (small
-        // genomes and saturated k-mer spaces show their solid hashes there); after that the bytes seen grow x4 per launch
-        // and, in front of every launch, T is capped ON THE DEVICE at 48*s' / (bytes seen after this launch),
-        // s' = s + 8*sqrt(s) + 16, i.e. ~20*s admissions per stage -- unless a tighten pass has meanwhile lowered T from
-        // solid hashes, or the table looks like a small genome sequenced deeply (cap_threshold_kernel).  The cap stays
-        // above the final s-th solid hash for any genome size while the error-free k-mer coverage c so far is <= ~17x,
-        // and s solid hashes appear below it as soon as c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window
-        // no x4 stage can jump over.  Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s
-        // exactness check and the retry with a 16x budget.
-        const bool filtered = sk->m > 1;
-        if (!last_slot) {
+    const bool filtered = sk->m > 1;
+    // The host never looks at T while pushing: every launch is followed by a tighten pass on the stream and nothing
+    // waits for a round trip.
+    // No multiplicity filter: launches grow by a factor G.  After a chunk of N k-mers T sits at the s-th smallest of
+    // them, hence the next, G times larger chunk admits ~G*s occurrences: G is what keeps that at a sixteenth of the
+    // table whatever the input is.
+    // Multiplicity filter (m > 1): T cannot follow the data before s hashes with count >= m exist, and until then
+    // every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is admitted whole (small
+    // genomes and saturated k-mer spaces show their solid hashes there); after that the bytes seen grow x4 per launch
+    // and, in front of every launch, T is capped ON THE DEVICE at 48*s' / (bytes seen after this launch),
+    // s' = s + 8*sqrt(s) + 16, i.e. ~20*s admissions per stage -- unless a tighten pass has meanwhile lowered T from
+    // solid hashes, or the table looks like a small genome sequenced deeply (cap_threshold_kernel; inside a push the
+    // tighten pass in front of the launch applies the cap itself, TableArgs::next_cap).  The cap stays
+    // above the final s-th solid hash for any genome size while the error-free k-mer coverage c so far is <= ~17x,
+    // and s solid hashes appear below it as soon as c / P[Poisson(c) >= m] <= 17 (c in 0.8 .. 16 for m = 3), a window
+    // no x4 stage can jump over.  Inputs with fewer than s solid k-mers in total, or m > ~8, end in finish()'s
+    // exactness check and the retry with a 16x budget.
+    struct Plan { uint32_t take; uint64_t cap; };
+    auto plan = [&](uint32_t tile, int launch) {
+        Plan p{ntiles - tile, 0};
+        if (launch != kMaxLaunchesPerPush - 1) {
             uint64_t chunk_bytes = next_chunk_bytes;
             if (filtered) {
                 // stages are defined on the bytes actually seen (pushes may be of any size): the uncapped first MiB,
@@ -438,21 +467,25 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
                 chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * bytes_pushed);
             }
             const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
-            if (chunk_tiles < take) take = (uint32_t)chunk_tiles;
+            if (chunk_tiles < p.take) p.take = (uint32_t)chunk_tiles;
         }
         if (filtered) {
-            const uint64_t after = pushed_before + std::min<uint64_t>(n, (uint64_t)(tile + take) * kTileBytes);
+            const uint64_t after = pushed_before + std::min<uint64_t>(n, (uint64_t)(tile + p.take) * kTileBytes);
             if (after > kUncappedBytes) {
                 const long double s_eff = (long double)sk->s + 8.0L * sqrtl((long double)sk->s) + 16.0L;
                 const long double cap_frac = 48.0L * s_eff * (long double)sk->admit_scale / (long double)after;
-                if (cap_frac < 1.0L) {
-                    const uint64_t cap = (uint64_t)(cap_frac * (long double)sk->hash_max);
-                    HIPCHK(launch_cap_threshold(sk->d_thresh, cap, sk->d_stats, g.stream)); // on the stream, in front of the tile launch
-                }
+                if (cap_frac < 1.0L) p.cap = std::max<uint64_t>(1, (uint64_t)(cap_frac * (long double)sk->hash_max));
             }
         }
+        return p;
+    };
+    uint32_t tile = 0;
+    int launch = 0;
+    Plan cur = plan(0, 0);
+    if (cur.cap) HIPCHK(launch_cap_threshold(sk->d_thresh, cur.cap, sk->d_stats, g.stream)); // first launch of a push: a launch of its own
+    while (tile < ntiles) {
         a.tile0 = tile;
-        a.ntiles = take;
+        a.ntiles = cur.take;
         a.ticket = sk->d_tickets + sk->tickets_used++;
         if (g.profiling) HIPCHK(hipEventRecord(g.ev0, g.stream));
         HIPCHK(launch_hash(sk->k, kfmt, a, g.stream));
@@ -465,18 +498,22 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
         }
         ++sk->launches;
         ++launch;
-        tile += take;
+        tile += cur.take;
         sk->table_dirty = true;
+        sk->table_sampled = false;
         bytes_pushed = pushed_before + std::min<uint64_t>(n, (uint64_t)tile * kTileBytes); // real bytes, not whole tiles: callers may push tiny spans
-        // tighten T from what has been seen (also after the last launch of a push: the next push starts from it).
-        // Sampled passes (big tables) leave the table marked dirty: finish() wants an exact one.
-        HIPCHK(launch_tighten(ta, g.stream));
-        if (ta.sample == 1) sk->table_dirty = false;
         if (!filtered && next_chunk_bytes < (1ull << 40)) {
             uint64_t G = sk->nslots / (16ull * sk->s);
             G = std::min<uint64_t>(std::max<uint64_t>(G, kChunkGrowth), 256);
             next_chunk_bytes *= G;
         }
+        if (tile < ntiles) cur = plan(tile, launch);
+        // tighten T from what has been seen (also after the last launch of a push: the next push starts from it).
+        // Sampled passes (big tables) leave the table marked dirty (an exact pass has not seen it) but sampled: see finish().
+        ta.next_cap = tile < ntiles ? cur.cap : 0;
+        HIPCHK(launch_tighten(ta, g.stream));
+        if (ta.sample == 1) sk->table_dirty = false;
+        else sk->table_sampled = true;
     }
     if (kfmt == 2 || repair) HIPCHK(launch_phase_verify(sk->d_phase_rec, ntiles, sk->d_stats, g.stream));
     return MHX_OK;
@@ -641,37 +678,43 @@ static int extract(mhx_sketcher *sk, uint64_t limit, uint32_t min_count, std::ve
     return fail(MHX_E_INTERNAL, "extract: output kept growing");
 }
 
-static void sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &cnts)
-{ // The extracted hashes are (close to) uniform below the threshold: one scatter into ~n..2n buckets by their leading
-  // bits (a shift, no division), then an insertion sort over the almost-sorted result (O(n) expected; any input still
-  // ends up sorted).
-    const size_t n = keys.size();
-    if (n < 2) return;
-    uint64_t hi = 0;
-    for (size_t i = 0; i < n; ++i) hi = keys[i] > hi ? keys[i] : hi;
-    int shift = 0;
-    while ((hi >> shift) >= 2 * n) ++shift;
-    const size_t nb = (size_t)(hi >> shift) + 1;
-    std::vector<uint32_t> start(nb + 1, 0);
-    for (size_t i = 0; i < n; ++i) ++start[(size_t)(keys[i] >> shift) + 1];
-    for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
-    std::vector<uint64_t> k2(n);
-    std::vector<uint32_t> c2(n);
-    for (size_t i = 0; i < n; ++i) {
-        const size_t d = start[(size_t)(keys[i] >> shift)]++;
-        k2[d] = keys[i];
-        c2[d] = cnts[i];
-    }
+static void insertion_pass(uint64_t *k2, uint32_t *c2, size_t n)
+{ // O(n + inversions): what is left to do after a scatter by leading bits
     for (size_t i = 1; i < n; ++i) {
         const uint64_t k = k2[i];
+        if (k2[i - 1] <= k) continue;
         const uint32_t c = c2[i];
         size_t j = i;
         while (j > 0 && k2[j - 1] > k) { k2[j] = k2[j - 1]; c2[j] = c2[j - 1]; --j; }
         k2[j] = k;
         c2[j] = c;
     }
-    keys.swap(k2);
-    cnts.swap(c2);
+}
+
+static void sort_pairs(const uint64_t *keys, const uint32_t *cnts, size_t n, SortScratch &sc)
+{ // The extracted hashes are (close to) uniform below the threshold: one scatter into ~n..2n buckets by their leading
+  // bits (a shift, no division), then an insertion sort over the almost-sorted result (O(n) expected; any input still
+  // ends up sorted).  Result in sc.keys / sc.cnts; the scratch vectors live with the sketcher (no page faults per call).
+    sc.keys.resize(n);
+    sc.cnts.resize(n);
+    if (n == 0) return;
+    uint64_t hi = 0;
+    for (size_t i = 0; i < n; ++i) hi = keys[i] > hi ? keys[i] : hi;
+    int shift = 0;
+    while ((hi >> shift) >= 2 * n) ++shift;
+    const size_t nb = (size_t)(hi >> shift) + 1;
+    sc.start.assign(nb + 1, 0);
+    uint32_t *start = sc.start.data();
+    for (size_t i = 0; i < n; ++i) ++start[(size_t)(keys[i] >> shift) + 1];
+    for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
+    uint64_t *k2 = sc.keys.data();
+    uint32_t *c2 = sc.cnts.data();
+    for (size_t i = 0; i < n; ++i) {
+        const size_t d = start[(size_t)(keys[i] >> shift)]++;
+        k2[d] = keys[i];
+        c2[d] = cnts[i];
+    }
+    insertion_pass(k2, c2, n);
 }
 
 static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
@@ -685,15 +728,27 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     const uint32_t cap = sk->fin_cap;
     uint64_t *d = sk->d_fin;
     const size_t fin_bytes = (4 + (size_t)cap + cap / 2) * sizeof(uint64_t);
+    static const bool dbg = getenv("MHX_FINISH_DEBUG") != nullptr; // stderr: where finish() spends its time
+    const auto t_begin = std::chrono::steady_clock::now();
+    bool want_exact = false;
   again:
-    if (sk->table_dirty) {
+    // big tables: the sampled pass behind the last launch left T at about the (s + 8 sqrt(s))-th solid hash, the block holds
+    // twice that, and the host keeps the first s -- a second pass over the table only if that turns out not to be so
+    if (sk->table_dirty && (want_exact || !sk->table_sampled)) {
         HIPCHK(launch_tighten(table_args(sk), g.stream));
         sk->table_dirty = false;
+        sk->table_sampled = false;
     }
     HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), g.stream));
-    HIPCHK(launch_extract(table_args(sk), 0, sk->m, d + 4, (uint32_t *)(d + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3, g.stream));
-    HIPCHK(hipMemcpyAsync(sk->h_fin, d, fin_bytes, hipMemcpyDeviceToHost, g.stream));
+    const bool ordered = sk->d_fin_ordered != nullptr;
+    HIPCHK(launch_extract(table_args(sk), 0, sk->m, d + 4, (uint32_t *)(d + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3, g.stream,
+                          ordered ? sk->d_order_buckets : nullptr, sk->order_log2));
+    if (ordered) // large sketches: the kernels put the block in hash order and store it into the pinned block themselves
+        HIPCHK(launch_order_block(d, cap, sk->order_log2, sk->d_order_buckets, sk->d_order_starts, sk->d_order_groups, sk->d_fin_ordered, sk->h_fin, g.stream));
+    else
+        HIPCHK(hipMemcpyAsync(sk->h_fin, d, fin_bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    const auto t_device = std::chrono::steady_clock::now();
     const uint64_t *h = sk->h_fin;
     const uint32_t n = (uint32_t)h[0];
     const uint64_t T = h[1], flags = h[2], maxkey = h[3];
@@ -703,6 +758,10 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
         goto again;
     }
     sk->unsettled.clear();
+    if (n > cap && sk->table_dirty && !want_exact) { // the sampled threshold was not the expected one: count exactly
+        want_exact = true;
+        goto again;
+    }
     sk->last_T = T;
     sk->bounded = (flags & kFlagStateBounded) != 0;
     sk->established = (flags & kFlagStateEstablished) != 0;
@@ -710,29 +769,51 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
     if (rc) return rc;
     std::vector<uint64_t> keys;
     std::vector<uint32_t> cnts;
-    if (n > cap) { // more entries below T than the result block holds: the general path
-        rc = extract(sk, T, sk->m, keys, cnts);
-        if (rc) return rc;
-    } else {
-        keys.assign(h + 4, h + 4 + n);
-        const uint32_t *hc = reinterpret_cast<const uint32_t *>(h + 4 + cap);
-        cnts.assign(hc, hc + n);
-    }
-    if (T == ~0ull && maxkey >= sk->m) { // the one hash value the table cannot hold
-        keys.push_back(~0ull);
-        cnts.push_back((uint32_t)maxkey);
+    const uint64_t *src_keys = h + 4; // the common case: sorted straight out of the pinned block
+    const uint32_t *src_cnts = reinterpret_cast<const uint32_t *>(h + 4 + cap);
+    size_t n_src = n;
+    const bool extra = T == ~0ull && maxkey >= sk->m; // the one hash value the table cannot hold
+    if (n > cap || extra) {
+        if (n > cap) { // more entries below T than the result block holds: the general path
+            rc = extract(sk, T, sk->m, keys, cnts);
+            if (rc) return rc;
+        } else {
+            keys.assign(src_keys, src_keys + n);
+            cnts.assign(src_cnts, src_cnts + n);
+        }
+        if (extra) {
+            keys.push_back(~0ull);
+            cnts.push_back((uint32_t)maxkey);
+        }
+        src_keys = keys.data();
+        src_cnts = cnts.data();
+        n_src = keys.size();
     }
     // exactness: either nothing was ever rejected (T still at its initial value), or at least s qualifying
     // hashes lie below T.  Fewer than s below a lowered T means the bound was too tight: a host-imposed cap
     // of the m > 1 phase (sk->bounded), or -- never seen, ~1e-9 per pass -- a sampled tighten pass that overshot.
-    if (keys.size() < sk->s && T < sk->hash_max)
+    if (n_src < sk->s && T < sk->hash_max)
         return fail(MHX_E_CAPACITY, "admission threshold was too tight for this input (%zu of %u sketch entries%s); recreate the sketcher with a larger table",
-                    keys.size(), sk->s, sk->bounded ? ", capped threshold" : "");
-    sort_pairs(keys, cnts);
-    const uint32_t nn = keys.size() < sk->s ? (uint32_t)keys.size() : sk->s;
-    memcpy(hashes, keys.data(), (size_t)nn * sizeof(uint64_t));
-    if (counts) memcpy(counts, cnts.data(), (size_t)nn * sizeof(uint32_t));
+                    n_src, sk->s, sk->bounded ? ", capped threshold" : "");
+    const auto t_copy = std::chrono::steady_clock::now();
+    const uint32_t nn = n_src < sk->s ? (uint32_t)n_src : sk->s;
+    bool in_order = ordered && src_keys == h + 4; // what the ordering kernels promise, checked
+    for (size_t i = 1; in_order && i < n_src; ++i) in_order = src_keys[i - 1] < src_keys[i];
+    if (in_order) {
+        memcpy(hashes, src_keys, (size_t)nn * sizeof(uint64_t));
+        if (counts) memcpy(counts, src_cnts, (size_t)nn * sizeof(uint32_t));
+    } else {
+        sort_pairs(src_keys, src_cnts, n_src, sk->sorted);
+        memcpy(hashes, sk->sorted.keys.data(), (size_t)nn * sizeof(uint64_t));
+        if (counts) memcpy(counts, sk->sorted.cnts.data(), (size_t)nn * sizeof(uint32_t));
+    }
     *n_out = nn;
+    if (dbg) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[mhx finish] device+copy %.0f us (block %zu bytes, %u entries), unpack %.0f us, sort+out %.0f us\n",
+                us(t_begin, t_device), fin_bytes, n, us(t_device, t_copy), us(t_copy, t_end));
+    }
     return MHX_OK;
 }
 
@@ -758,9 +839,9 @@ static int mhx_sketcher_export_impl(mhx_sketcher *sk, uint64_t limit, uint64_t *
     if (keys.size() > cap) return fail(MHX_E_CAPACITY, "export: %zu entries, buffer holds %u", keys.size(), cap);
     if (!keys.empty()) {
         if (!hashes || !counts) return fail(MHX_E_ARG, "null output buffer");
-        sort_pairs(keys, cnts);
-        memcpy(hashes, keys.data(), keys.size() * sizeof(uint64_t));
-        memcpy(counts, cnts.data(), cnts.size() * sizeof(uint32_t));
+        sort_pairs(keys.data(), cnts.data(), keys.size(), sk->sorted);
+        memcpy(hashes, sk->sorted.keys.data(), keys.size() * sizeof(uint64_t));
+        memcpy(counts, sk->sorted.cnts.data(), cnts.size() * sizeof(uint32_t));
     }
     return MHX_OK;
 }

@@ -419,17 +419,26 @@ __global__ __launch_bounds__(256) void table_tighten_kernel(const TableArgs a)
     }
     __syncthreads();
     if (t == 0) {
-        a.stats[kStatOccupied] = tot_s[0] * (a.sample > 1 ? a.sample : 1);
-        a.stats[kStatSolid] = tot_s[1] * (a.sample > 1 ? a.sample : 1);
+        const uint64_t occupied = tot_s[0] * (a.sample > 1 ? a.sample : 1), solid = tot_s[1] * (a.sample > 1 ? a.sample : 1);
+        a.stats[kStatOccupied] = occupied;
+        a.stats[kStatSolid] = solid;
         *a.done = 0;
         const uint32_t cut = cut_s;
+        uint64_t now = T;
+        bool established = a.min_mult > 1 && a.stats[kStatEstablished];
         if (cut != 0xFFFFFFFFu && lz <= 52) {
             const uint64_t edge = (((uint64_t)cut + 1) << (53 - lz)) - 1; // last value of bin `cut`
             if (edge < T) {
-                *a.thresh = edge;
-                if (a.min_mult > 1) a.stats[kStatEstablished] = 1; // from now on T follows the solid hashes: no more caps
+                now = edge;
+                if (a.min_mult > 1) { a.stats[kStatEstablished] = 1; established = true; } // from now on T follows the solid hashes: no more caps
             }
         }
+        // the byte-count cap in front of the NEXT launch of the same push (cap_threshold_kernel's rule, without its launch)
+        if (a.next_cap && !established && !(occupied > 0 && solid * 5 >= occupied) && now > a.next_cap) {
+            now = a.next_cap;
+            a.stats[kStatBounded] = 1;
+        }
+        if (now < T) *a.thresh = now;
     }
 }
 
@@ -508,12 +517,20 @@ hipError_t launch_reset(const TableArgs &a, uint64_t t_init, uint32_t *tickets, 
     return hipGetLastError();
 }
 
+__device__ __forceinline__ int order_shift(uint64_t T, uint32_t log2_buckets)
+{ // finish(), large sketches (see launch_order_block): the bucket of a hash is its leading log2_buckets bits below T's top bit
+    const int bits = 64 - __clzll((long long)(T | 1ull)); // T < 2^bits
+    return bits > (int)log2_buckets ? bits - (int)log2_buckets : 0;
+}
+
 __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, uint64_t limit, uint32_t min_count,
                                                             uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
                                                             uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
-                                                            uint64_t *limit_out, uint64_t *maxkey_out)
+                                                            uint64_t *limit_out, uint64_t *maxkey_out,
+                                                            uint32_t *order_cursor, uint32_t order_log2)
 {
     if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
+    const int bucket_shift = order_shift(limit, order_log2);
     if (blockIdx.x == 0 && threadIdx.x == 0 && limit_out) *limit_out = limit;
     // optional: occurrences of the one hash value the table cannot hold (2^64 - 1), summed over the replicas
     if (maxkey_out && blockIdx.x == 0 && threadIdx.x < kStatReplicas) {
@@ -561,7 +578,11 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
             if (threadIdx.x == 0) base = atomicAdd(out_n, n);
             __syncthreads();
             for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
-                if (base + j < cap) { out_keys[base + j] = bkeys[j]; out_cnts[base + j] = bcnts[j]; }
+                if (base + j < cap) {
+                    out_keys[base + j] = bkeys[j];
+                    out_cnts[base + j] = bcnts[j];
+                    if (order_cursor) atomicAdd(&order_cursor[bkeys[j] >> bucket_shift], 1u); // bucket sizes for launch_order_block
+                }
             __syncthreads();
             if (threadIdx.x == 0) nbuf = 0;
             __syncthreads();
@@ -571,12 +592,149 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
 
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
-                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st)
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor, uint32_t order_log2)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
-                       out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out);
+                       out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out, order_cursor, order_log2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// finish(), large sketches: the result block in hash order, written straight into the pinned host block.  The
+// extracted hashes are close to uniform below the threshold T (block word [1]), so a counting sort on their leading
+// log2(nbuckets) bits below T's top bit puts all but a few neighbours in place: the extract kernel counts the buckets as
+// it appends (order_cursor), order_scan_kernel turns counts into start positions (per group of 1024 buckets; the group
+// totals are summed by whoever needs them), order_scatter_kernel places the
+// entries, order_place_kernel -- one thread per bucket -- ranks the handful of entries of its bucket, stores them at
+// their final position in host memory (neighbouring threads, neighbouring addresses) and clears its counter for the
+// next finish().  Nothing is read back in between and no copy follows; the host checks the order of what it received
+// (buckets beyond kOrderMaxBucket entries are passed through unranked) and sorts itself if it has to.
+// Block layout as written by table_extract_kernel: [0] n  [1] T  [2] flags  [3] max-key count  [4 .. 4+cap) hashes
+// [4+cap ..) counts.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kOrderMaxBucket = 48;
+constexpr uint32_t kScanChunk = 1024;    // counters per workgroup of the scan (256 threads x one uint4)
+constexpr uint32_t kMaxScanGroups = 1024; // -> at most 2^20 buckets
+
+// exclusive prefix sum over the 256 threads of a workgroup (value per thread) -> prefix, and the total for everybody
+__device__ __forceinline__ uint32_t scan256(uint32_t value, uint32_t *wave_sums /*[4] LDS*/, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = value;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) wave_sums[wave] = v;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t x = wave_sums[w];
+        if (w < wave) base += x;
+        all += x;
+    }
+    total = all;
+    return base + v - value;
+}
+
+// counts -> start positions WITHIN each group of kScanChunk buckets (coalesced, one uint4 per thread), group totals aside;
+// the consumers add the groups in front themselves (group_bases)
+__global__ __launch_bounds__(256) void order_scan_kernel(uint32_t *cursor, uint32_t *starts, uint32_t *group_total)
+{
+    __shared__ uint32_t wave_sums[4];
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint4 c = reinterpret_cast<const uint4 *>(cursor)[v];
+    uint32_t total;
+    uint32_t run = scan256(c.x + c.y + c.z + c.w, wave_sums, total);
+    uint4 o;
+    o.x = run; run += c.x;
+    o.y = run; run += c.y;
+    o.z = run; run += c.z;
+    o.w = run;
+    reinterpret_cast<uint4 *>(cursor)[v] = o;
+    reinterpret_cast<uint4 *>(starts)[v] = o;
+    if (threadIdx.x == 0) group_total[blockIdx.x] = total;
+}
+
+// sbase[g] = entries in the groups in front of group g, sbase[ngroups] = all of them (256 threads, ngroups <= 1024)
+__device__ __forceinline__ void group_bases(const uint32_t *group_total, uint32_t ngroups, uint32_t *sbase, uint32_t *wave_sums)
+{
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t g = 4u * threadIdx.x + j;
+        c[j] = g < ngroups ? group_total[g] : 0u;
+        sum += c[j];
+    }
+    uint32_t total;
+    uint32_t run = scan256(sum, wave_sums, total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t g = 4u * threadIdx.x + j;
+        if (g < ngroups) sbase[g] = run;
+        run += c[j];
+    }
+    if (threadIdx.x == 0) sbase[ngroups] = total;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *blk, uint32_t cap, uint32_t log2_buckets, uint32_t *cursor,
+                                                            const uint32_t *group_total, uint64_t *out)
+{
+    __shared__ uint32_t sbase[kMaxScanGroups + 1], wave_sums[4];
+    group_bases(group_total, (1u << log2_buckets) / kScanChunk, sbase, wave_sums);
+    const uint32_t n = blk[0] < cap ? (uint32_t)blk[0] : cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = blk[4 + i];
+    const uint32_t b = (uint32_t)(key >> order_shift(blk[1], log2_buckets));
+    const uint32_t d = sbase[b / kScanChunk] + atomicAdd(&cursor[b], 1u);
+    if (d >= cap) return; // cannot happen with counters that start from zero
+    out[4 + d] = key;
+    reinterpret_cast<uint32_t *>(out + 4 + cap)[d] = reinterpret_cast<const uint32_t *>(blk + 4 + cap)[i];
+}
+
+__global__ __launch_bounds__(256) void order_place_kernel(const uint64_t *blk, const uint64_t *grouped, uint32_t cap, uint32_t nbuckets,
+                                                          uint32_t *cursor, const uint32_t *starts, const uint32_t *group_total, uint64_t *host_blk)
+{
+    __shared__ uint32_t sbase[kMaxScanGroups + 1], wave_sums[4];
+    group_bases(group_total, nbuckets / kScanChunk, sbase, wave_sums);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < 4) host_blk[b] = blk[b];
+    if (b >= nbuckets) return;
+    cursor[b] = 0;
+    const uint32_t n = blk[0] < cap ? (uint32_t)blk[0] : cap;
+    uint32_t lo = sbase[b / kScanChunk] + starts[b], hi = sbase[(b + 1) / kScanChunk] + starts[b + 1]; // starts[nbuckets] = 0 for good
+    lo = lo < n ? lo : n;
+    hi = hi < n ? hi : n;
+    const uint32_t *gc = reinterpret_cast<const uint32_t *>(grouped + 4 + cap);
+    uint32_t *hc = reinterpret_cast<uint32_t *>(host_blk + 4 + cap);
+    const bool rank_them = hi - lo <= kOrderMaxBucket;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t key = grouped[4 + i];
+        uint32_t rank = i - lo;
+        if (rank_them && hi - lo > 1) {
+            rank = 0;
+            for (uint32_t j = lo; j < hi; ++j) rank += grouped[4 + j] < key ? 1u : 0u; // hashes of one table are distinct
+        }
+        host_blk[4 + lo + rank] = key;
+        hc[lo + rank] = gc[i];
+    }
+}
+
+hipError_t launch_order_block(const uint64_t *blk, uint32_t cap, uint32_t log2_buckets, uint32_t *cursor, uint32_t *starts,
+                              uint32_t *group_total, uint64_t *grouped, uint64_t *host_blk, hipStream_t st)
+{
+    const uint32_t nb = 1u << log2_buckets; // 2^10 .. 2^20
+    if (nb < kScanChunk || nb / kScanChunk > kMaxScanGroups) return hipErrorInvalidValue;
+    const unsigned blocks = (cap + 255) / 256;
+    hipLaunchKernelGGL(order_scan_kernel, dim3(nb / kScanChunk), dim3(256), 0, st, cursor, starts, group_total);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, st, blk, cap, log2_buckets, cursor, group_total, grouped);
+    hipLaunchKernelGGL(order_place_kernel, dim3(nb / 256), dim3(256), 0, st, blk, grouped, cap, nb, cursor, starts, group_total, host_blk);
     return hipGetLastError();
 }
 

@@ -1081,3 +1081,21 @@ def test_record_without_qualities_in_front_of_a_tile_border(tmp_path):
     got = mo.read_msh(tmp_path / "c.msh").references[0].hashes
     want, _ = mo.bruteforce_sketch(reads[:i] + [filler, cut_seq] + reads[i:], 21, 1000, 1)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("s,m", [(8192, 1), (120_000, 1), (300_000, 2)])
+def test_large_sketches_come_back_in_hash_order_from_the_device(s, m):
+    """s >= 8192: finish() has the device order the result block (counting sort on the leading bits, ranks inside the
+    buckets) and store it into the pinned block; the host only checks the order.  Sizes with 2^14, 2^17 and 2^19 buckets,
+    a second finish() on the same table (the bucket counters must be back at zero), and a sketch shorter than s."""
+    genome = synth.make_genome(1_500_000, seed=41)
+    fq = synth.make_fastq(genome, 120_000, 150, seed=42, device="cpu").numpy()
+    sk = engine.Sketcher(21, s, m, expected_bytes=fq.size)
+    sk.push_host(fq, engine.FMT_FASTQ4)
+    got, cnt = sk.finish()
+    again, cnt2 = sk.finish()
+    sk.close()
+    _, (want, _) = oracle_sketch(fq.tobytes(), 21, s, m)
+    assert len(got) == min(s, len(want)) and np.array_equal(got, want)
+    assert np.array_equal(again, got) and np.array_equal(cnt2, cnt)
+    assert np.all(cnt >= m)

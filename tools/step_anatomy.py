@@ -2,7 +2,7 @@
 a stream sync), against the HIP-event time of the tile kernels alone.   python tools/step_anatomy.py [--k K --s S --m M]"""
 import argparse, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from auriclass_amd import engine, synth
 
 ap = argparse.ArgumentParser()
