@@ -104,8 +104,8 @@ def stock_mash_run(sample: np.ndarray, rb: int, k: int, s: int, m: int, cores: i
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (weak scaling)")
     ap.add_argument("--total-reads", type=int, default=0, help="reads in all, split over the GPUs (strong scaling); 0 = off")
     ap.add_argument("--read-len", type=int, default=150)

@@ -11,7 +11,7 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
-tail -1 $OUT/trace.log > $OUT/bench_line_under_trace.json
+grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/bench_line_under_trace.json
 STEPS=7   # passes over the input per PMC run: 2 warmup + 2 timed + 3 event-timed (bench.py)
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
             "sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH" \
