@@ -40,7 +40,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
     } else {
         for (int it = 0; it < iters; ++it) {
             const uint32_t g = (tid + it * 256) % (kGroupsPerTile - 8);
-            acc += process_group<21>(sm, g, T, false, ins);
+            acc += process_group<21>(sm, g, T, admission_limit(T), ins);
         }
     }
     const uint64_t t1 = clock64();
@@ -50,9 +50,9 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
 
 template <int MODE> void run(const char *name, unsigned long long *d, uint32_t desync)
 {
-    const int iters = 64;
-    printf("%-28s", name);
-    for (int bpc = 1; bpc <= 3; ++bpc) {
+    const int iters = 256;
+    printf("%-28s\n", name);
+    for (int bpc = 1; bpc <= 7; ++bpc) {
         const int blocks = 256 * bpc;
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0ull, desync);
         hipDeviceSynchronize();
@@ -65,14 +65,16 @@ template <int MODE> void run(const char *name, unsigned long long *d, uint32_t d
         hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         double s = 0; for (int i = 0; i < blocks * 4; ++i) s += (double)h[2 + i];
         const double per_window = s / (blocks * 4) / (iters * 8.0);
-        printf("  %d wg/CU: %7.1f cyc/window/wave (%6.1f per SIMD) %.3f ms", bpc, per_window, per_window / bpc, ms);
+        const double windows = (double)blocks * 256.0 * iters * 8.0;
+        printf("  %d wg/CU: %7.1f ticks/window/wave (%6.1f per SIMD)  %.3f ms  %.1f G windows/s  %.2f ns per wave-window per SIMD\n", bpc, per_window, per_window / bpc, ms,
+               windows / (ms * 1e-3) / 1e9, ms * 1e6 / (windows / 64.0 / 1024.0));
     }
     printf("\n");
 }
 
 int main()
 {
-    unsigned long long *d; hipMalloc(&d, (2 + 1024 * 4) * 8); hipMemset(d, 0, (2 + 1024 * 4) * 8);
+    unsigned long long *d; hipMalloc(&d, (2 + 2048 * 4) * 8); hipMemset(d, 0, (2 + 2048 * 4) * 8);
     run<0>("murmur3_h1<21> only", d, 0);
     run<1>("process_group<21> (8 windows)", d, 0);
     run<1>("process_group, waves desynchronised", d, 50000);
