@@ -243,12 +243,14 @@ def main() -> None:
         # HBM bytes per step from the PMC passes (profiles/traffic.json), only quoted for the very
         # workload they were collected on
         traffic = None
+        valu_instr = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
                 tj = json.loads(tf.read_text())
                 if tj.get("algorithmic_bytes_per_step") == nbytes and (args.k, args.s, args.m) == (21, 1000, 1):
                     traffic = tj.get("sketch_tile_kernel_hbm_bytes_per_step")
+                    valu_instr = tj.get("sketch_tile_kernel_valu_wave_instructions_per_step")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -256,6 +258,13 @@ def main() -> None:
                     "kernel": "sketch_tile_kernel", "kernel_ms_per_step": round(kernel_ms, 4),
                     "launches_per_step": st["launches"], "algorithmic_bytes_per_step": nbytes,
                     "kmers_per_s": round(st["kmers"] / (kernel_ms / 1e3) / 1e9, 3), "kmers_unit": "G k-mers/s"}
+        if valu_instr:
+            # the operative limit: wave64 integer VALU instructions issue at ~4 cycles each per SIMD;
+            # instruction count from the PMC pass of the same workload, time measured live, clock taken as 2.4 GHz
+            simds = 256 * 4
+            roofline["valu_issue"] = {"wave_instructions_per_step": valu_instr,
+                                      "cycles_per_instruction_per_simd": round(kernel_ms * 1e-3 * 2.4e9 * simds / valu_instr, 3),
+                                      "issue_cost_cycles": 4.0, "clock_ghz_assumed": 2.4}
 
         # ---- CPU baseline + parity on a bounded sample of the same workload -------------------
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is an N=1 figure; at N>1 every rank's host cores are busy

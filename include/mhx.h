@@ -99,7 +99,9 @@ int mhx_sketcher_reset(mhx_sketcher *sk);
 
 /* Feed one record-aligned span.  The device pointer must be readable up to the next
  * 16-byte boundary past n (true for any hipMalloc/torch allocation).  Asynchronous on
- * the engine's stream; the buffer must stay valid until finish()/sync(). */
+ * the engine's stream; the buffer must stay valid AND unchanged until mhx_sketcher_finish() or
+ * mhx_sketcher_sync() has returned -- a synchronisation of the stream alone is not enough: FASTQ spans
+ * whose reads are longer than ~2.7 kb are read a second time by a pass that those two calls start. */
 int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int fmt);
 int mhx_sketcher_push_host(mhx_sketcher *sk, const void *h_bytes, uint64_t n, int fmt);
 int mhx_sketcher_sync(mhx_sketcher *sk);
