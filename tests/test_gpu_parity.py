@@ -1099,3 +1099,62 @@ def test_large_sketches_come_back_in_hash_order_from_the_device(s, m):
     assert len(got) == min(s, len(want)) and np.array_equal(got, want)
     assert np.array_equal(again, got) and np.array_equal(cnt2, cnt)
     assert np.all(cnt >= m)
+
+
+@pytest.mark.parametrize("seed", _seeds(6))
+def test_randomised_mixtures_of_short_and_long_reads(seed):
+    """Streams in which stretches of short reads (tiles that find their line phase by themselves) alternate with
+    stretches of reads of up to 12 kb (tiles left to the look-back repair pass), pushed in one to four spans from device
+    memory or through the host staging buffer, LF or CRLF, quality lines that begin with '@' or '+'."""
+    import torch
+
+    rng = np.random.default_rng(9900 + seed)
+    k = int(rng.choice([11, 16, 21, 27, 31, 32]))
+    m = int(rng.choice([1, 1, 2, 3]))
+    s = int(rng.choice([100, 1000, 10000]))
+    genome = synth.make_genome(int(rng.integers(20_000, 150_000)), seed=300 + seed).tobytes()
+    nl = b"\r\n" if rng.random() < 0.25 else b"\n"
+    reads, recs = [], []
+    for stretch in range(int(rng.integers(2, 7))):
+        long_ones = bool(rng.integers(0, 2))
+        for _ in range(int(rng.integers(5, 40)) if long_ones else int(rng.integers(50, 1500))):
+            L = int(rng.integers(2_500, 12_000)) if long_ones else int(rng.integers(1, 400))
+            L = min(L, len(genome) - 1)
+            p0 = int(rng.integers(0, len(genome) - L))
+            r = genome[p0:p0 + L]
+            q = bytearray(rng.choice(np.frombuffer(b"@+I5#", np.uint8), size=L).tobytes())
+            reads.append(r)
+            recs.append(b"@x%d" % len(recs) + nl + r + nl + b"+" + nl + bytes(q) + nl)
+    n_push = int(rng.integers(1, 5))
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(recs) + 1, n_push - 1))) if n_push > 1 else []
+    bounds = [0] + cuts + [len(recs)]
+    blobs = [b"".join(recs[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+    blobs = [b for b in blobs if b]
+    via_host = bool(rng.integers(0, 2))
+    devs = [] if via_host else [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in blobs]
+    torch.cuda.synchronize()
+    got = None
+    for scale in (1, 16, 256, 4096):
+        sk = engine.Sketcher(k, s, m, expected_bytes=sum(len(b) for b in blobs), budget_scale=scale)
+        for i, b in enumerate(blobs):
+            if via_host:
+                sk.push_host(b, engine.FMT_FASTQ4)
+            else:
+                sk.push_device(devs[i].data_ptr(), len(b), engine.FMT_FASTQ4)
+        try:
+            got, _ = sk.finish()
+        except engine.EngineError as e:
+            sk.close()
+            if e.code != engine.MHX_E_CAPACITY:
+                raise
+            continue
+        st = sk.stats()
+        n_long = sk.record_count()
+        sk.close()
+        break
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(b"".join(blobs))
+    want, _ = ref.finish()
+    assert got is not None and np.array_equal(got, want), (k, s, m)
+    assert st["lines"] == 4 * len(reads) and st["flags"] == 0
+    assert n_long == ref.records == sum(1 for r in reads if len(r) >= k)

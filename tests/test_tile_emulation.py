@@ -273,3 +273,31 @@ def test_fastq_with_crlf_line_ends(emul, k):
     assert int(stats[7]) == ref.records == sum(1 for r in reads if len(r) >= k)
     got, stats = run_emul(emul, data[:-1], k, fmt=1)     # ends with a bare CR
     assert int(stats[7]) == ref.records
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_damaged_fastq_never_gets_a_wrong_phase_past_the_checks(emul, seed):
+    """Lines deleted, duplicated or cut, bytes overwritten: whenever some tile's self-found phase differs from the running
+    line count, the chain check or the per-record layout check must have fired (the engine then drops the result and
+    parses with the record parser), so a silently mis-phased tile is impossible."""
+    rng = np.random.default_rng(4000 + seed)
+    reads = random_reads(rng, 900, 20, 260)
+    lines = fastq_bytes(rng, reads).split(b"\n")[:-1]
+    for _ in range(int(rng.integers(1, 4))):
+        i = int(rng.integers(0, len(lines)))
+        what = int(rng.integers(0, 5))
+        if what == 0:
+            del lines[i]
+        elif what == 1:
+            lines.insert(i, lines[i])
+        elif what == 2:
+            lines[i] = lines[i][: len(lines[i]) // 2]
+            del lines[i + 1: i + 1 + int(rng.integers(0, 3))]
+        elif what == 3:
+            lines[i] = bytes(rng.choice(np.frombuffer(b"@+ACGT\n", np.uint8), size=max(1, len(lines[i]))))
+        else:
+            lines[i] = b"@" + lines[i][1:] if lines[i] else b"@"
+    data = b"\n".join(lines) + b"\n"
+    _, stats = run_emul(emul, data, 21, fmt=1, lead=int(rng.integers(0, 20000)))
+    if int(stats[5]) & 1:
+        assert (int(stats[5]) & 2) or (int(stats[3]) & 2)
