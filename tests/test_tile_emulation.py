@@ -301,3 +301,20 @@ def test_damaged_fastq_never_gets_a_wrong_phase_past_the_checks(emul, seed):
     _, stats = run_emul(emul, data, 21, fmt=1, lead=int(rng.integers(0, 20000)))
     if int(stats[5]) & 1:
         assert (int(stats[5]) & 2) or (int(stats[3]) & 2)
+
+
+def test_tiles_of_very_short_lines(emul):
+    """Reads of 0..3 bases under one-letter names: ~6000 newlines per 16 KiB tile; counts of records with >= k bases and
+    the layout check included."""
+    rng = np.random.default_rng(13)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 4)))) for _ in range(30000)]
+    data = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in reads)
+    for k in (1, 2, 3):
+        got, stats = run_emul(emul, data, k, fmt=1, lead=5)
+        assert int(stats[3]) == 0 and int(stats[5]) == 0
+        assert int(stats[2]) == 4 * len(reads)
+        assert int(stats[7]) == sum(1 for r in reads if len(r) >= k)
+        assert np.array_equal(got, oracle_hashes(reads, k))
+    bad = data.replace(b"\n+\n", b"\n-\n", 1)   # one plus line damaged
+    _, stats = run_emul(emul, bad, 2, fmt=1)
+    assert int(stats[3]) & 2
