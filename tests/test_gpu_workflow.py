@@ -2,6 +2,7 @@
 (/root/reference/tests/test_correct_workflow.py:41-234, tests/test_failing_workflow.py:51-128,
 and the CI `cmp report.tsv` lines of .github/workflows/test.yaml:58-77)."""
 import tempfile
+from pathlib import Path
 
 import pytest
 
@@ -163,3 +164,29 @@ def test_the_binding_stub_printed_in_INTEGRATION_md_works_as_written(refcwd, mon
     assert open("stub_ref.msh", "rb").read() == (REFDATA / "ref_sketch.msh").read_bytes()
     empty = run(["mash", "sketch", "-r", "-m", "3", "-o", "stub_e.msh", "-k", "27", "-s", "50000", "tests/data/test_empty_1.fq.gz"])
     assert b"ERROR: Did not find fasta records in" in empty.stderr
+
+
+def test_bench_prints_the_contract_line():
+    """`python bench.py` on a small workload: one JSON line with the keys the driver reads, the roofline and CPU-baseline
+    objects, and the in-run parity check against the CPU oracle."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "200000",
+                          "--cpu-sample-reads", "100000", "--cpu-cores", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["unit"] == "Gbases/s" and j["higher_is_better"] is True
+    assert j["value"] > 1.0 and abs(j["value"] - 200000 * 150 / (j["ms_per_step"] * 1e-3) / 1e9) < 0.01 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0
+    assert j["parity_on_sample"] is True
