@@ -52,7 +52,8 @@ hipError_t launch_order_block(const uint64_t *blk, uint32_t cap, uint32_t log2_b
 hipError_t launch_phase_verify(const uint8_t *rec, uint32_t ntiles, uint64_t *stats, hipStream_t st);
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
-                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor = nullptr, uint32_t order_log2 = 0);
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor = nullptr, uint32_t order_log2 = 0,
+                          uint64_t *hdr_dev = nullptr, uint64_t *hdr_host = nullptr, uint32_t *ticket = nullptr);
 bool hash_k_supported(int k);
 
 // FASTA on the device (mhx_fasta.hip): raw file bytes -> dense sequence stream + record separator positions.

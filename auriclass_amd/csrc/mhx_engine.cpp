@@ -287,6 +287,7 @@ int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_byte
     sk->fin_cap = (s + 16u * (uint32_t)sqrt((double)s) + 4096u + 1u) & ~1u; // what a sampled threshold leaves, with room (finish())
     const size_t fin_bytes = (4 + (size_t)sk->fin_cap + sk->fin_cap / 2) * sizeof(uint64_t);
     A((void **)&sk->d_fin, fin_bytes);
+    if (e == hipSuccess) e = hipMemset(sk->d_fin, 0, 4 * sizeof(uint64_t)); // the header words are zero between two finish() calls
     if (s >= kDeviceOrderMinSketch) { // below that the host's bucket sort costs less than three more launches
         sk->order_log2 = 12;
         while ((1u << sk->order_log2) < sk->fin_cap && sk->order_log2 < 20) ++sk->order_log2;
@@ -739,14 +740,17 @@ static int mhx_sketcher_finish_impl(mhx_sketcher *sk, uint64_t *hashes, uint32_t
         sk->table_dirty = false;
         sk->table_sampled = false;
     }
-    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), g.stream));
     const bool ordered = sk->d_fin_ordered != nullptr;
-    HIPCHK(launch_extract(table_args(sk), 0, sk->m, d + 4, (uint32_t *)(d + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3, g.stream,
-                          ordered ? sk->d_order_buckets : nullptr, sk->order_log2));
-    if (ordered) // large sketches: the kernels put the block in hash order and store it into the pinned block themselves
+    if (ordered) { // large sketches: the kernels put the block in hash order and store it into the pinned block themselves
+        HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), g.stream));
+        HIPCHK(launch_extract(table_args(sk), 0, sk->m, d + 4, (uint32_t *)(d + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3, g.stream,
+                              sk->d_order_buckets, sk->order_log2));
         HIPCHK(launch_order_block(d, cap, sk->order_log2, sk->d_order_buckets, sk->d_order_starts, sk->d_order_groups, sk->d_fin_ordered, sk->h_fin, g.stream));
-    else
-        HIPCHK(hipMemcpyAsync(sk->h_fin, d, fin_bytes, hipMemcpyDeviceToHost, g.stream));
+    } else { // one kernel, nothing else: the entries go straight into the pinned block, the workgroup that finishes last
+             // adds the header words (kept on the device while they are being accumulated) and clears them for the next call
+        HIPCHK(launch_extract(table_args(sk), 0, sk->m, sk->h_fin + 4, (uint32_t *)(sk->h_fin + 4 + cap), cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3,
+                              g.stream, nullptr, 0, d, sk->h_fin, sk->d_done));
+    }
     HIPCHK(hipStreamSynchronize(g.stream));
     const auto t_device = std::chrono::steady_clock::now();
     const uint64_t *h = sk->h_fin;

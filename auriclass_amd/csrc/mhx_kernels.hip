@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
                                                             uint64_t *out_keys, uint32_t *out_cnts, uint32_t cap,
                                                             uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                                                             uint64_t *limit_out, uint64_t *maxkey_out,
-                                                            uint32_t *order_cursor, uint32_t order_log2)
+                                                            uint32_t *order_cursor, uint32_t order_log2,
+                                                            uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket)
 {
     if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
     const int bucket_shift = order_shift(limit, order_log2);
@@ -588,16 +589,39 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
             __syncthreads();
         }
     }
+    // finish(): the four header words [n, T, flags, max-key count] at hdr_dev go to the pinned block (whose payload the
+    // flushes above have written directly) and are cleared for the next call, by the workgroup that finishes last --
+    // no header memset in front of the kernel, no copy command behind it.  Same hand-over as the tighten pass: every
+    // wave waits for its own memory operations, one lane releases and takes the ticket, the last workgroup reads the
+    // words with agent-scope loads.
+    if (!hdr_host) return;
+    __shared__ uint32_t last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last_s = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (threadIdx.x < 4) {
+        const uint64_t v = __hip_atomic_load(&hdr_dev[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hdr_host[threadIdx.x] = v;
+        __hip_atomic_store(&hdr_dev[threadIdx.x], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) *ticket = 0;
 }
 
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
-                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor, uint32_t order_log2)
+                          uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor, uint32_t order_log2,
+                          uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
-                       out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out, order_cursor, order_log2);
+                       out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out, order_cursor, order_log2,
+                       hdr_dev, hdr_host, ticket);
     return hipGetLastError();
 }
 
