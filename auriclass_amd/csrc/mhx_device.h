@@ -23,6 +23,7 @@ struct HashArgs {
     uint64_t *stats;
     uint32_t *need_lookback; // FMT 2: set to 1 by a tile that could not find its line phase by itself (and did nothing else)
     uint32_t repair;         // FMT 1: repair pass -- tiles that CAN find their phase by themselves only publish it
+    uint32_t queue_candidates; // kernel form: windows that pass the admission test are queued and finished after the hash loop (large sketches)
     uint8_t *phase_rec;      // FMT 2 / repair: one phase_record() per tile of the span (0: phase unknown), for phase_verify_kernel
 };
 

@@ -403,6 +403,8 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
     a.keys = sk->d_keys; a.cnts = sk->d_cnts; a.slot_mask = sk->nslots - 1; a.stats = sk->d_stats;
     a.need_lookback = sk->d_need;
     a.repair = repair ? 1u : 0u;
+    static const char *force_queue = getenv("MHX_QUEUE_CANDIDATES"); // "0" / "1": diagnostic override
+    a.queue_candidates = force_queue ? (uint32_t)(force_queue[0] == '1') : (uint32_t)(sk->s >= kDeviceOrderMinSketch);
     const uint64_t ntiles64 = (a.end + kTileBytes - 1) / kTileBytes;
     if (ntiles64 > 0x7FFFFFFFull) return fail(MHX_E_ARG, "span too large for one push (%llu bytes)", (unsigned long long)n);
     const uint32_t ntiles = (uint32_t)ntiles64;

@@ -48,6 +48,30 @@ struct DeviceInserter {
     }
 };
 
+// Not inlined on purpose: the window finished here needs ~40 registers of its own (two strands, eight words each, and
+// the hash); inside the kernel body they would be the hash loop's problem.
+template <int K> __device__ __noinline__ uint32_t finish_candidate(const TileSmem &sm, uint32_t code, uint64_t T, DeviceInserter ins)
+{
+    return process_deferred<K>(sm, code, T, ins);
+}
+
+// What the hash loop does with a candidate window: queue it behind the tile's work list (TileSmem), or -- queue full,
+// which takes more than ~1000 candidates in a tile: the first launches of a sketch, when T still admits every hash --
+// finish it on the spot.
+template <int K> struct CandidateQueue {
+    TileSmem &sm;
+    uint32_t first, cap; // list[first .. first + cap) is free
+    uint64_t T;
+    DeviceInserter ins;
+    __device__ __forceinline__ void operator()(uint32_t group, int window) const
+    {
+        const uint32_t code = (group << 3) | (uint32_t)window;
+        const uint32_t slot = atomicAdd(&sm.misc[7], 1u);
+        if (slot < cap) sm.list[first + slot] = (uint16_t)code;
+        else if (finish_candidate<K>(sm, code, T, ins)) atomicAdd(&sm.misc[4], 1u);
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // Decoupled look-back over per-tile newline counts (wave 0 of the block).
 // tile_state[t] is ONE naturally aligned 8-byte word {flag:32 | value:32} written by one
@@ -157,7 +181,7 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t value, uint32_t *wa
 #ifndef MHX_MIN_WAVES
 #define MHX_MIN_WAVES 7   // 72 VGPRs: seven waves per SIMD, matching the seven workgroups per CU the LDS footprint admits
 #endif
-template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) void sketch_tile_kernel(const HashArgs a)
+template <int K, int FMT, bool QUEUE> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) void sketch_tile_kernel(const HashArgs a)
 {
     __shared__ TileSmem sm;
     constexpr bool FASTQ = (FMT != 0), LOOKBACK = (FMT == 1), SELFSYNC = (FMT == 2);
@@ -178,7 +202,7 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     }
     const uint64_t tile_off = (uint64_t)tile * kTileBytes;
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(a.stats) + (tile % kStatReplicas) * kStatCount;
-    if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; sm.misc[5] = 0; }
+    if (tid == 0) { sm.misc[3] = 0; sm.misc[4] = 0; sm.misc[5] = 0; sm.misc[7] = 0; }
 #ifdef MHX_STAMPS
     uint64_t stamp_prev = clock64();
     int stamp_idx = 0;
@@ -259,8 +283,15 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
     const uint64_t T = *a.thresh;
     const uint32_t limit = admission_limit(T);
     DeviceInserter ins{reinterpret_cast<unsigned long long *>(a.keys), a.cnts, a.slot_mask, stats};
+    const uint32_t qcap = (uint32_t)kGroupsPerTile - nitems; // QUEUE: the work list's unused tail holds the candidate queue
+    CandidateQueue<K> queue{sm, nitems, qcap, T, ins};
     uint32_t ninsert = 0;
-    for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K>(sm, sm.list[it], T, limit, ins);
+    for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K, QUEUE>(sm, sm.list[it], T, limit, ins, queue);
+    if (QUEUE) { // the candidates the loop has queued, one per lane
+        __syncthreads();
+        const uint32_t ncand = sm.misc[7] < qcap ? sm.misc[7] : qcap;
+        for (uint32_t c = tid; c < ncand; c += kBlock) ninsert += finish_candidate<K>(sm, sm.list[nitems + c], T, ins);
+    }
     if (ninsert) atomicAdd(&sm.misc[4], ninsert);
     __syncthreads();
     MHX_STAMP(); // 5: work loop
@@ -274,9 +305,14 @@ template <int K, int FMT> __global__ __launch_bounds__(kBlock, MHX_MIN_WAVES) vo
 
 template <int K> static hipError_t launch_k(int fmt, const HashArgs &a, hipStream_t st)
 {
-    if (fmt == 1) hipLaunchKernelGGL((sketch_tile_kernel<K, 1>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
-    else if (fmt == 2) hipLaunchKernelGGL((sketch_tile_kernel<K, 2>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((sketch_tile_kernel<K, 0>), dim3(a.ntiles), dim3(kBlock), 0, st, a);
+    // a.queue_candidates: large sketches (many windows pass the admission test) finish their candidates after the hash
+    // loop, one per lane; small ones where they are found (process_group_regs)
+#define MHX_LAUNCH(FMT_) do { if (a.queue_candidates) hipLaunchKernelGGL((sketch_tile_kernel<K, FMT_, true>), dim3(a.ntiles), dim3(kBlock), 0, st, a); \
+                              else hipLaunchKernelGGL((sketch_tile_kernel<K, FMT_, false>), dim3(a.ntiles), dim3(kBlock), 0, st, a); } while (0)
+    if (fmt == 1) MHX_LAUNCH(1);
+    else if (fmt == 2) MHX_LAUNCH(2);
+    else MHX_LAUNCH(0);
+#undef MHX_LAUNCH
     return hipGetLastError();
 }
 

@@ -38,6 +38,11 @@ struct uint4 { uint32_t x, y, z, w; };
 namespace mhx {
 
 constexpr int kMapWords = (kTileBytes + kHaloBytes) / 32 + 2; // words of a 1-bit-per-byte map of tile + halo (+2 look-ahead)
+// Windows whose partial hash passes the admission test are not finished where they are found -- one candidate lane would
+// take the other 63 through the cold code (hash tail, exact compare, base check, two atomics: ~100 instructions), and
+// with a large sketch (s = 50 000: one window in 230 below T) that happens in every fourth wave-iteration -- but queued
+// as (group << 3) | window in the part of the work list the tile's items leave free (list[nitems ..)) and finished
+// together after the hash loop, one per lane (process_deferred).  A window that finds the queue full is finished at once.
 struct TileSmem {
     uint4 bytes[(kTileBytes + kHaloBytes) / 16];      // staged stream bytes
     uint32_t valid[kGroupsPerTile / 4];                // byte g = candidate-start mask of group g
@@ -49,7 +54,7 @@ struct TileSmem {
         uint32_t maps[2 * kMapWords];
     };
     uint32_t cnt[16];                                  // wave partials of the two workgroup scans
-    uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts
+    uint32_t misc[8];                                  // 0: line base, 1: #items, 2: tile id, 3: k-mers, 4: inserts, 5: long records, 7: #queued candidates
 };
 
 MHX_HD uint32_t *tile_nlmap(TileSmem &sm) { return sm.maps; }             // 1 bit per byte: newline
@@ -504,7 +509,7 @@ MHX_HD void phase_compact(TileSmem &sm, int tid, uint32_t excl)
 
 // ASCII complement of four folded bases at once: bits 1..2 of a base tell 'A','C','T','G' apart (0,1,2,3) and the
 // complement comes out of a 4-byte table in one v_perm_b32.  Bytes that are not A/C/G/T come out as one of
-// the four letters as well; a window that holds one never reaches the table (window_is_acgt).
+// the four letters as well; a window that holds one never reaches the table (process_deferred checks the bases).
 MHX_HD uint32_t complement4(uint32_t u) { return perm_lut(kLutComp, base_index(u)); }
 
 // 64 bits starting at byte offset `off` (compile-time) of the dword array a
@@ -605,10 +610,16 @@ template <int K, int J, int ND> MHX_HD bool window_is_acgt(const uint32_t (&chun
     return (m & want) == want;
 }
 
-// ins(h) is called for every window that is a candidate start (bit of vm), consists of A/C/G/T only and whose hash
-// is <= T.  `limit` = admission_limit(T).
-template <int K, class Ins>
-MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint32_t vm, uint64_t T, uint32_t limit, Ins &ins)
+// vm: bits 0..7 the candidate-start mask of the group, bits 8.. the group's number (it rides along in the same register:
+// the hash loop has none to spare).  A window that is a valid start and whose partial hash passes the admission test
+// (`limit` = admission_limit(T); 32-bit hashes: the exact low word against T) is
+//   QUEUE = false: finished where it is found: ins(h) if its bases are all A/C/G/T and h <= T (returns their number);
+//   QUEUE = true : handed to cand(group, J) (queued, finished later by process_deferred).
+// Two forms because each costs the other's workload something: with a small sketch (s = 1000, one candidate in 10^4
+// windows) the inline form is 0.8 % faster (the queue's cold branch changes the register allocation of the hot path by
+// one v_mov per window); with a large one (s = 50 000) the queue is 7 % faster.
+template <int K, bool QUEUE, class Ins, class Cand>
+MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint32_t vm, uint64_t T, uint32_t limit, Ins &ins, Cand &cand)
 {
     constexpr int ND = GroupGeom<K>::ND;
     uint32_t U[ND + 1], R[ND + 1], Wr[ND + 1], Cc[ND + 1];
@@ -633,8 +644,12 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
         /* necessary condition of h <= T, one add + one compare (32-bit hashes: the exact low word) */ \
         const bool candidate = kHash32 ? tail.low32() <= (uint32_t)T : tail.high_bound() <= limit; \
         if (MHX_UNLIKELY(candidate)) {                                                        \
-            const uint64_t h = kHash32 ? (uint64_t)tail.low32() : tail.finish();              \
-            if (((vm >> J) & 1u) && h <= T && window_is_acgt<K, J, ND>(U)) { ins(h); ++ninserted; }   \
+            if constexpr (QUEUE) {                                                            \
+                if ((vm >> J) & 1u) cand(vm >> 8, J);                                         \
+            } else {                                                                          \
+                const uint64_t h = kHash32 ? (uint64_t)tail.low32() : tail.finish();          \
+                if (((vm >> J) & 1u) && h <= T && window_is_acgt<K, J, ND>(U)) { ins(h); ++ninserted; } \
+            }                                                                                 \
         }                                                                                     \
     }
     MHX_WINDOW(0) MHX_WINDOW(1) MHX_WINDOW(2) MHX_WINDOW(3) MHX_WINDOW(4) MHX_WINDOW(5) MHX_WINDOW(6) MHX_WINDOW(7)
@@ -644,16 +659,57 @@ MHX_HD uint32_t process_group_regs(const uint32_t (&src)[GroupGeom<K>::ND], uint
 }
 
 // work item g of a staged tile (LDS source)
-template <int K, class Ins>
-MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, uint32_t limit, Ins &ins)
+template <int K, bool QUEUE, class Ins, class Cand>
+MHX_HD uint32_t process_group(const TileSmem &sm, uint32_t g, uint64_t T, uint32_t limit, Ins &ins, Cand &cand)
 {
     constexpr int ND = GroupGeom<K>::ND;
-    const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g];
+    const uint32_t vm = reinterpret_cast<const uint8_t *>(sm.valid)[g] | (g << 8);
     const uint32_t *p = reinterpret_cast<const uint32_t *>(sm.bytes) + 2 * g;
     uint32_t src[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) src[d] = p[d];
-    return process_group_regs<K>(src, vm, T, limit, ins);
+    return process_group_regs<K, QUEUE>(src, vm, T, limit, ins, cand);
+}
+
+// A queued candidate (code = (group << 3) | window), finished from the staged bytes with a window offset known only at
+// run time: the K bytes by funnel shifts out of LDS, base check, reverse complement of those K bytes, the exact strand
+// comparison, the whole hash.  Slower per window than the unrolled hot path, but run one candidate per lane.
+template <int K, class Ins> MHX_HD uint32_t process_deferred(const TileSmem &sm, uint32_t code, uint64_t T, Ins &ins)
+{
+    constexpr int NW = (K + 3) / 4;
+    constexpr uint32_t tail_mask = (K % 4) ? (1u << (8 * (K % 4))) - 1u : 0xFFFFFFFFu;
+    const uint32_t pos = 8u * (code >> 3) + (code & 7u);
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(sm.bytes) + (pos >> 2);
+    const uint32_t sh = 8u * (pos & 3u);
+    uint32_t wf[8], wr[8], rev[NW + 1];
+    uint32_t ok_bits = 0;
+#pragma unroll
+    for (int d = 0; d < NW; ++d) {
+        const uint32_t raw = funnel_bits(b[d + 1], b[d], sh);
+        ok_bits |= flags_to_nibble(acgt_flags(raw)) << (4 * d);
+        wf[d] = raw & 0xDFDFDFDFu; // fold case
+    }
+    constexpr uint32_t want = (uint32_t)((1ull << K) - 1ull);
+    if ((ok_bits & want) != want) return 0u; // mash skips every window that holds anything but A/C/G/T
+    wf[NW - 1] &= tail_mask;
+#pragma unroll
+    for (int d = NW; d < 8; ++d) wf[d] = 0u;
+    // reverse complement: the 4*NW bytes reversed and complemented put the window's K bytes behind 4*NW - K bytes of padding
+#pragma unroll
+    for (int d = 0; d < NW; ++d) rev[d] = __builtin_bswap32(complement4(wf[NW - 1 - d]));
+    rev[NW] = 0u;
+    constexpr uint32_t pad_bits = 8u * (4 * NW - K);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) wr[d] = d < NW ? (pad_bits ? funnel_bits(rev[d + 1], rev[d], pad_bits) : rev[d]) : 0u;
+    const bool rc = rc_is_smaller_full<NW>(wf, wr);
+    uint32_t w[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) w[d] = rc ? wr[d] : wf[d];
+    const Murmur3Tail tail = murmur3_core<K>(w);
+    const uint64_t h = K <= 16 ? (uint64_t)tail.low32() : tail.finish();
+    if (h > T) return 0u;
+    ins(h);
+    return 1u;
 }
 
 } // namespace mhx

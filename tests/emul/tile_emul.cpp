@@ -56,7 +56,29 @@ static void run_tiles(const uint8_t *base, uint64_t begin, uint64_t end, uint64_
         for (int t = 0; t < kBlock; ++t) { uint32_t items = 0; stats[kStatKmers] += phase_runs<K>(sm, t, items); ex2[t] = run; run += items; }
         for (int t = 0; t < kBlock; ++t) phase_compact(sm, t, ex2[t]);
         const uint32_t nitems = sm.misc[1];
-        for (uint32_t it = 0; it < nitems; ++it) stats[kStatInserts] += process_group<K>(sm, sm.list[it], T, admission_limit(T), ins);
+        // the candidate queue behind the work list, as on the device; odd tiles get a queue of 5 entries so that the
+        // "queue full: finish at once" path runs too
+        struct Queue {
+            TileSmem &sm; uint32_t first, cap; uint64_t T; VecInserter &ins; uint64_t *inserts;
+            void operator()(uint32_t group, int window) const
+            {
+                const uint32_t code = (group << 3) | (uint32_t)window;
+                const uint32_t slot = sm.misc[7]++;
+                if (slot < cap) sm.list[first + slot] = (uint16_t)code;
+                else *inserts += process_deferred<K>(sm, code, T, ins);
+            }
+        };
+        sm.misc[7] = 0;
+        uint32_t qcap = (uint32_t)kGroupsPerTile - nitems;
+        if ((tile & 1u) && qcap > 5u) qcap = 5u;
+        Queue queue{sm, nitems, qcap, T, ins, &stats[kStatInserts]};
+        if (tile % 3u == 2u) { // every third tile: the form that finishes its candidates where they are found
+            for (uint32_t it = 0; it < nitems; ++it) stats[kStatInserts] += process_group<K, false>(sm, sm.list[it], T, admission_limit(T), ins, queue);
+        } else {
+            for (uint32_t it = 0; it < nitems; ++it) process_group<K, true>(sm, sm.list[it], T, admission_limit(T), ins, queue);
+            const uint32_t ncand = sm.misc[7] < qcap ? sm.misc[7] : qcap;
+            for (uint32_t c = 0; c < ncand; ++c) stats[kStatInserts] += process_deferred<K>(sm, sm.list[nitems + c], T, ins);
+        }
         stats[kStatLines] += tile_total;
     }
 }

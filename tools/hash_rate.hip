@@ -7,6 +7,7 @@
 #include "../auriclass_amd/csrc/mhx_tile.h"
 using namespace mhx;
 
+struct CountCand { uint64_t *acc; __device__ void operator()(uint32_t g, int w) const { *acc += g + w; } };
 struct CountIns { unsigned long long *sink; __device__ void operator()(uint64_t h) { atomicAdd(sink, (unsigned long long)h); } };
 
 template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, uint64_t T, uint32_t desync)
@@ -40,7 +41,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
     } else {
         for (int it = 0; it < iters; ++it) {
             const uint32_t g = (tid + it * 256) % (kGroupsPerTile - 8);
-            acc += process_group<21>(sm, g, T, admission_limit(T), ins);
+            CountCand cc{&acc}; acc += process_group<21, false>(sm, g, T, admission_limit(T), ins, cc);
         }
     }
     const uint64_t t1 = clock64();
