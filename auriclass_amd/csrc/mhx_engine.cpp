@@ -487,6 +487,14 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
     Plan cur = plan(0, 0);
     if (cur.cap) HIPCHK(launch_cap_threshold(sk->d_thresh, cur.cap, sk->d_stats, g.stream)); // first launch of a push: a launch of its own
     while (tile < ntiles) {
+        // Kernel form of this launch (process_group_regs): candidates are queued when many windows will pass the admission
+        // test -- a large sketch, or an early launch whose threshold still stems from little data (T ~ s-th smallest of
+        // the k-mers seen so far, ~0.4 per FASTQ byte: above ~3 candidates in 10^4 windows the queue wins); the very first
+        // launch, which admits everything, and the long launches of a small sketch finish them where they are found.
+        if (!force_queue) {
+            const long double expected_rate = bytes_pushed ? (long double)sk->s / (0.4L * (long double)bytes_pushed) : 0.0L;
+            a.queue_candidates = (uint32_t)(sk->s >= kDeviceOrderMinSketch || (bytes_pushed && expected_rate > 3e-4L));
+        }
         a.tile0 = tile;
         a.ntiles = cur.take;
         a.ticket = sk->d_tickets + sk->tickets_used++;
