@@ -38,11 +38,12 @@ struct uint4 { uint32_t x, y, z, w; };
 namespace mhx {
 
 constexpr int kMapWords = (kTileBytes + kHaloBytes) / 32 + 2; // words of a 1-bit-per-byte map of tile + halo (+2 look-ahead)
-// Windows whose partial hash passes the admission test are not finished where they are found -- one candidate lane would
-// take the other 63 through the cold code (hash tail, exact compare, base check, two atomics: ~100 instructions), and
-// with a large sketch (s = 50 000: one window in 230 below T) that happens in every fourth wave-iteration -- but queued
-// as (group << 3) | window in the part of the work list the tile's items leave free (list[nitems ..)) and finished
-// together after the hash loop, one per lane (process_deferred).  A window that finds the queue full is finished at once.
+// The queue form of the kernel (large sketches, early launches; process_group_regs<K, true>): windows whose partial
+// hash passes the admission test are not finished where they are found -- one candidate lane would take the other 63
+// through the cold code (hash tail, exact compare, base check, two atomics: ~100 instructions), and with s = 50 000 (one
+// window in 230 below T) that happens in every fourth wave-iteration -- but queued as (group << 3) | window in the part of
+// the work list the tile's items leave free (list[nitems ..)) and finished together after the hash loop, one per lane
+// (process_deferred).  A window that finds the queue full is finished at once.
 struct TileSmem {
     uint4 bytes[(kTileBytes + kHaloBytes) / 16];      // staged stream bytes
     uint32_t valid[kGroupsPerTile / 4];                // byte g = candidate-start mask of group g
