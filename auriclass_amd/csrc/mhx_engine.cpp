@@ -492,7 +492,9 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
         // the k-mers seen so far, ~0.4 per FASTQ byte: above ~3 candidates in 10^4 windows the queue wins); the very first
         // launch, which admits everything, and the long launches of a small sketch finish them where they are found.
         if (!force_queue) {
-            const long double expected_rate = bytes_pushed ? (long double)sk->s / (0.4L * (long double)bytes_pushed) : 0.0L;
+            long double expected_rate = bytes_pushed ? (long double)sk->s / (0.4L * (long double)bytes_pushed) : 0.0L;
+            // staged phase of the multiplicity filter: the threshold sits at the byte-count cap until solid hashes take over
+            if (cur.cap) expected_rate = std::max(expected_rate, (long double)cur.cap / (long double)sk->hash_max);
             a.queue_candidates = (uint32_t)(sk->s >= kDeviceOrderMinSketch || (bytes_pushed && expected_rate > 3e-4L));
         }
         a.tile0 = tile;
