@@ -495,7 +495,8 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
             long double expected_rate = bytes_pushed ? (long double)sk->s / (0.4L * (long double)bytes_pushed) : 0.0L;
             // staged phase of the multiplicity filter: the threshold sits at the byte-count cap until solid hashes take over
             if (cur.cap) expected_rate = std::max(expected_rate, (long double)cur.cap / (long double)sk->hash_max);
-            a.queue_candidates = (uint32_t)(sk->s >= kDeviceOrderMinSketch || (bytes_pushed && expected_rate > 3e-4L));
+            // (a sequence stream fills the work list -- every group of a tile is an item --, which leaves the queue no room)
+            a.queue_candidates = (uint32_t)(kfmt != 0 && (sk->s >= kDeviceOrderMinSketch || (bytes_pushed && expected_rate > 3e-4L)));
         }
         a.tile0 = tile;
         a.ntiles = cur.take;
