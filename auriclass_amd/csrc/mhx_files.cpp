@@ -296,10 +296,15 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
     // a big single-member .gz (what sequencers write) is decoded by several threads (mhx_pinflate.cpp); what follows its
     // first member, small files and anything the parallel decoder declines go through the sequential decoder
     std::unique_ptr<ParallelGunzip> par;
+    std::unique_ptr<BgzfReader> bgzf; // bgzip output: independent blocks of <= 64 KiB, decoded side by side
     if (own) {
         if (!read_whole_file(path, zbytes, GzInflater::kInputPad)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
         const size_t zn = zbytes.size() - GzInflater::kInputPad;
         if (decode_threads >= 2) {
+            bgzf.reset(new BgzfReader());
+            if (!bgzf->start(zbytes.data(), zn, decode_threads)) bgzf.reset();
+        }
+        if (!bgzf && decode_threads >= 2) {
             par.reset(new ParallelGunzip());
             if (!par->start(zbytes.data(), zn, decode_threads)) par.reset();
         }
@@ -337,7 +342,21 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
         bool eof = false;
         while (n < kIngestChunk) {
             long got;
-            if (par) {
+            if (bgzf) {
+                const size_t r = bgzf->read(d + n, kIngestChunk - n);
+                if (r == (size_t)-1) got = -1;
+                else if (r == 0) { // end of the run of BGZF blocks (each one's CRC and length verified): the rest, if any, sequentially
+                    const size_t off = bgzf->consumed_input(), zn = zbytes.size() - GzInflater::kInputPad;
+                    bgzf.reset();
+                    inf.set_input(zbytes.data() + off, zn - off);
+                    produced = 0;
+                    if (off >= zn) { eof = true; break; }
+                    continue;
+                } else {
+                    got = (long)r;
+                    produced += r;
+                }
+            } else if (par) {
                 const size_t r = par->read(d + n, kIngestChunk - n);
                 if (r == (size_t)-1) got = -1;
                 else if (r == 0) { // end of the first member (CRC and length verified): the rest, if any, sequentially

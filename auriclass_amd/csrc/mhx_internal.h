@@ -99,6 +99,29 @@ class ParallelGunzip {
     Impl *impl_;
 };
 
+// ---- BGZF (bgzip): a gzip file of independent members of <= 64 KiB, each announcing its size (mhx_pinflate.cpp) ------
+// mash reads such a file like any multi-member gzip (zlib's gzread); here the members are decoded side by side.
+class BgzfReader {
+  public:
+    BgzfReader();
+    ~BgzfReader();
+    BgzfReader(const BgzfReader &) = delete;
+    BgzfReader &operator=(const BgzfReader &) = delete;
+    // The compressed file (GzInflater::kInputPad readable bytes behind data[n - 1]).  false: the file does not start
+    // with a run of BGZF blocks worth the threads (use the other decoders).
+    bool start(const uint8_t *data, size_t n, int threads);
+    // Output of that run of blocks, in order: bytes copied, 0 at its end (every block's CRC-32 and length verified),
+    // (size_t)-1 on error.
+    size_t read(uint8_t *dst, size_t want);
+    // after the end: offset just behind the last BGZF block (other members / padding may follow there)
+    size_t consumed_input() const;
+    const std::string &error() const;
+
+  private:
+    struct Impl;
+    Impl *impl_;
+};
+
 // ---- statistics / text (mhx_text.cpp) ---------------------------------------------------
 double binomial_cdf(uint64_t x, double p, uint64_t n);        // P[X <= x]
 double binomial_sf_ge(uint64_t x, double p, uint64_t n);      // P[X >= x]

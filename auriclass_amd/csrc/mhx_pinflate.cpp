@@ -543,6 +543,157 @@ size_t ParallelGunzip::read(uint8_t *dst, size_t want)
     return got;
 }
 
+// ---- BGZF -----------------------------------------------------------------------------------------------------------
+// Every block is a gzip member of its own (no match reaches into another block) whose header carries the block's
+// compressed size (extra subfield 'B','C') and whose trailer its CRC-32 and length: the chain of blocks is walked
+// without decoding anything, which gives every block its place in the output, and the blocks are then decoded by the
+// worker threads with the ordinary byte decoder, each into a scratch buffer (the decoder may write a few bytes past a
+// block's end) and from there into its group's buffer.  Groups of kGroup blocks (<= 32 MiB) are the unit handed to the
+// consumer; the workers run at most kSlots groups ahead of it.
+struct BgzfReader::Impl {
+    struct Block { size_t off; uint32_t csize, isize; uint32_t out_off; }; // out_off: inside the block's group
+    static constexpr size_t kGroup = 512, kSlots = 3;
+    const uint8_t *z = nullptr;
+    size_t n = 0, end_off = 0;
+    std::vector<Block> blocks;
+    std::vector<uint32_t> group_bytes;         // output bytes of group g
+    std::vector<std::vector<uint8_t>> slot;    // kSlots group buffers
+    std::vector<uint32_t> left;                // blocks of group g still being decoded
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<size_t> next_block{0};
+    size_t consumed_groups = 0;                // groups the consumer is done with
+    bool abort = false, failed = false;
+    std::string error;
+    size_t cur_group = 0, cur_off = 0;         // consumer position
+
+    // size of the BGZF block at z[off..), 0 if there is none
+    static uint32_t block_size(const uint8_t *z, size_t n, size_t off)
+    {
+        if (n - off < 28 || z[off] != 0x1f || z[off + 1] != 0x8b || z[off + 2] != 8 || !(z[off + 3] & 4)) return 0;
+        const uint32_t xlen = z[off + 10] | (z[off + 11] << 8);
+        if (n - off < 12 + (size_t)xlen) return 0;
+        for (uint32_t p = 0; p + 4 <= xlen;) {
+            const uint8_t *f = z + off + 12 + p;
+            const uint32_t slen = f[2] | (f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && p + 6 <= xlen) {
+                const uint32_t total = (uint32_t)(f[4] | (f[5] << 8)) + 1u;
+                return total >= 12 + xlen + 8 && total <= n - off ? total : 0;
+            }
+            p += 4 + slen;
+        }
+        return 0;
+    }
+    void worker()
+    {
+        GzInflater inf;
+        std::vector<uint8_t> scratch(65536 + GzInflater::kOvershoot + 64);
+        for (;;) {
+            const size_t i = next_block.fetch_add(1);
+            if (i >= blocks.size()) return;
+            const size_t g = i / kGroup;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return abort || g < consumed_groups + kSlots; });
+                if (abort) return;
+            }
+            const Block &b = blocks[i];
+            bool ok = true;
+            if (b.isize) {
+                inf.set_input(z + b.off, b.csize); // one member: header, deflate stream, CRC-32 and length (both checked)
+                size_t got = 0;
+                // room for one byte more than the block announces: the decoder then runs through the end-of-block symbol
+                // and the trailer (CRC-32, length) by itself; a stream that produces that byte is refused
+                while (ok && !inf.done()) {
+                    const size_t r = inf.inflate(scratch.data() + got, (size_t)b.isize + 1 - got, scratch.data());
+                    if (r == (size_t)-1 || (r == 0 && !inf.done())) ok = false;
+                    else got += r;
+                    if (got > b.isize) ok = false;
+                }
+                if (ok && got != b.isize) ok = false;
+                if (ok) memcpy(slot[g % kSlots].data() + b.out_off, scratch.data(), b.isize);
+            }
+            std::lock_guard<std::mutex> lk(m);
+            if (!ok && !failed) { failed = true; error = inf.error().empty() ? "corrupt BGZF block" : inf.error(); }
+            if (--left[g] == 0 || !ok) cv.notify_all();
+        }
+    }
+    ~Impl()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            abort = true;
+        }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+
+BgzfReader::BgzfReader() : impl_(new Impl) {}
+BgzfReader::~BgzfReader() { delete impl_; }
+const std::string &BgzfReader::error() const { return impl_->error; }
+size_t BgzfReader::consumed_input() const { return impl_->end_off; }
+
+bool BgzfReader::start(const uint8_t *z, size_t n, int threads)
+{
+    Impl &p = *impl_;
+    if (threads < 2 || n < 28) return false;
+    size_t off = 0;
+    uint32_t in_group = 0;
+    while (off < n) {
+        const uint32_t len = Impl::block_size(z, n, off);
+        if (!len) break;
+        const uint8_t *t = z + off + len - 4;
+        const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > 65536) break; // not BGZF after all
+        if (p.blocks.size() % Impl::kGroup == 0) { p.group_bytes.push_back(0); in_group = 0; }
+        p.blocks.push_back({off, len, isize, in_group});
+        in_group += isize;
+        p.group_bytes.back() = in_group;
+        off += len;
+    }
+    if (p.blocks.size() < 8) { p.blocks.clear(); p.group_bytes.clear(); return false; } // a handful of blocks: not worth the threads
+    p.z = z;
+    p.n = n;
+    p.end_off = off;
+    const size_t ngroups = p.group_bytes.size();
+    p.left.resize(ngroups);
+    for (size_t g = 0; g < ngroups; ++g) p.left[g] = (uint32_t)std::min(Impl::kGroup, p.blocks.size() - g * Impl::kGroup);
+    p.slot.resize(Impl::kSlots);
+    for (auto &s : p.slot) s.resize(Impl::kGroup * 65536);
+    for (int t = 0; t < threads; ++t) p.workers.emplace_back([&p] { p.worker(); });
+    return true;
+}
+
+size_t BgzfReader::read(uint8_t *dst, size_t want)
+{
+    Impl &p = *impl_;
+    size_t got = 0;
+    while (got < want && p.cur_group < p.group_bytes.size()) {
+        const size_t g = p.cur_group;
+        {
+            std::unique_lock<std::mutex> lk(p.m);
+            p.cv.wait(lk, [&] { return p.failed || p.left[g] == 0; });
+            if (p.failed) return (size_t)-1;
+        }
+        const size_t take = std::min<size_t>(want - got, p.group_bytes[g] - p.cur_off);
+        memcpy(dst + got, p.slot[g % Impl::kSlots].data() + p.cur_off, take);
+        got += take;
+        p.cur_off += take;
+        if (p.cur_off == p.group_bytes[g]) {
+            {
+                std::lock_guard<std::mutex> lk(p.m);
+                p.consumed_groups = g + 1;
+            }
+            p.cv.notify_all();
+            ++p.cur_group;
+            p.cur_off = 0;
+        }
+    }
+    return got;
+}
+
 } // namespace mhx
 
 // ---- C ABI: whole-buffer gunzip with several threads (tests, and callers that hold the compressed bytes) ----------
@@ -557,8 +708,21 @@ extern "C" int mhx_gunzip_buffer_mt(const void *gz, size_t n, void *out, size_t 
         memcpy(in.data(), gz, n);
         uint8_t *dst = (uint8_t *)out;
         size_t total = 0, off = 0;
+        BgzfReader bgzf;
+        if (threads >= 2 && bgzf.start(in.data(), n, threads)) { // bgzip output: independent blocks, decoded side by side
+            std::vector<uint8_t> piece(4u << 20);
+            for (;;) {
+                const size_t room = dst && total < cap ? cap - total : 0;
+                const size_t got = room >= piece.size() ? bgzf.read(dst + total, room) : bgzf.read(piece.data(), piece.size());
+                if (got == (size_t)-1) return fail(MHX_E_FORMAT, "gunzip: %s", bgzf.error().c_str());
+                if (got == 0) break;
+                if (room < piece.size() && dst && total < cap) memcpy(dst + total, piece.data(), std::min(got, cap - total));
+                total += got;
+            }
+            off = bgzf.consumed_input();
+        }
         ParallelGunzip par;
-        if (threads >= 2 && par.start(in.data(), n, threads)) {
+        if (off == 0 && threads >= 2 && par.start(in.data(), n, threads)) {
             std::vector<uint8_t> piece(4u << 20);
             for (;;) {
                 const size_t room = dst && total < cap ? cap - total : 0;

@@ -69,7 +69,21 @@ static long run_par_case(const uint8_t *z, size_t n, int threads)
     memcpy(in, z, n);
     memset(in + n, 0, GzInflater::kInputPad);
     long total = 0;
+    bool was_bgzf = false;
     {
+        mhx::BgzfReader bg; // bgzip's blocks first, as the ingest does
+        if (bg.start(in, n, threads)) {
+            was_bgzf = true;
+            std::vector<uint8_t> piece(1u << 16);
+            for (;;) {
+                const size_t got = bg.read(piece.data(), piece.size());
+                if (got == (size_t)-1) { total = -1; break; }
+                if (got == 0) break;
+                total += (long)got;
+            }
+        }
+    }
+    if (!was_bgzf) {
         mhx::ParallelGunzip par;
         if (!par.start(in, n, threads)) total = -2;
         else {

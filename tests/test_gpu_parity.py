@@ -1158,3 +1158,22 @@ def test_randomised_mixtures_of_short_and_long_reads(seed):
     assert got is not None and np.array_equal(got, want), (k, s, m)
     assert st["lines"] == 4 * len(reads) and st["flags"] == 0
     assert n_long == ref.records == sum(1 for r in reads if len(r) >= k)
+
+
+def test_bgzf_fastq_through_the_ingest(tmp_path):
+    """A bgzip'ed FASTQ (independent 64 KiB members): the ingest decodes its blocks side by side; mash reads the same file
+    through zlib as one multi-member stream.  Followed by an ordinary gzip member, as concatenated files are."""
+    import gzip
+
+    from tests.test_lib_cpu import _bgzf
+
+    genome = synth.make_genome(200_000, seed=51)
+    a = synth.make_fastq(genome, 120_000, 150, seed=52, device="cpu").numpy().tobytes()      # 38 MB: ~580 blocks, two groups
+    b = synth.make_fastq(genome, 5_000, 100, seed=53, device="cpu", first_index=500_000).numpy().tobytes()
+    p = tmp_path / "reads.fastq.gz"
+    p.write_bytes(_bgzf(a, 4) + gzip.compress(b, 6))
+    engine.sketch_files([p], 21, 2000, tmp_path / "o.msh", reads=True, min_mult=2)
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    ref, (want, _) = oracle_sketch(a + b, 21, 2000, 2)
+    assert np.array_equal(got.hashes, want)
+    assert got.comment == ref.comment()

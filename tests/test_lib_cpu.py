@@ -226,7 +226,8 @@ def test_inflate_under_address_sanitizer(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     rng = np.random.default_rng(12)
     text = _fastq_like(rng, 3000)   # ~200 KB compressed, a dozen dynamic blocks: the parallel decoder cuts it into segments
-    seeds = {"dyn.gz": _gz(text, 6), "fixed_stored.gz": _gz(text[:3000], 0) + _gz(b"ACGT" * 50, 9, filename="x.fq")}
+    seeds = {"dyn.gz": _gz(text, 6), "fixed_stored.gz": _gz(text[:3000], 0) + _gz(b"ACGT" * 50, 9, filename="x.fq"),
+             "blocks.bgzf.gz": _bgzf(text[:60_000], 6, 3000)}   # 20 BGZF blocks: BgzfReader's threads
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                MHX_PINFLATE_MIN="1", MHX_PINFLATE_SEGMENT="8192")   # the parallel decoder engages on these small seeds too
     for i, (name, z) in enumerate(seeds.items()):
@@ -308,3 +309,45 @@ def test_msh_writer_equals_the_oracle_writer_on_random_containers(lib, tmp_path)
         p = tmp_path / "x.msh"
         engine.msh_write(p, k, s, [r.name for r in refs], [r.comment for r in refs], [r.length for r in refs], [r.hashes for r in refs])
         assert p.read_bytes() == mo.msh_bytes(sk)
+
+
+def _bgzf(data: bytes, level: int = 6, block: int = 0xFF00, eof_block: bool = True) -> bytes:
+    """bgzip's container: gzip members of <= 64 KiB each with a 'BC' extra subfield holding the member's size."""
+    import struct
+    import zlib
+
+    out = bytearray()
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        d = c.compress(chunk) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+        out += struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    if eof_block:
+        out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return bytes(out)
+
+
+def test_bgzf_blocks_are_decoded_side_by_side():
+    """bgzip output (independent members that announce their size): decoded by several threads, every block's CRC-32 and
+    length checked; other members may follow the run of blocks; a handful of blocks is left to the other decoders."""
+    import gzip
+
+    rng = np.random.default_rng(21)
+    text = bytes(rng.choice(np.frombuffer(b"ACGT\n@+I#5", np.uint8), size=3_300_000))
+    for level, block in ((1, 0xFF00), (6, 0xFF00), (9, 10_000), (0, 65_280)):
+        z = _bgzf(text, level, block)
+        assert gzip.decompress(z) == text
+        for threads in (2, 5):
+            assert engine.gunzip(z, threads=threads, size_hint=len(text)) == text
+    z = _bgzf(text)
+    assert engine.gunzip(z + gzip.compress(b"an ordinary member behind the blocks\n"), threads=4) == text + b"an ordinary member behind the blocks\n"
+    assert engine.gunzip(_bgzf(text[:200_000], eof_block=False), threads=4) == text[:200_000]          # 4 blocks: not worth the threads
+    assert engine.gunzip(_bgzf(b""), threads=4) == b""
+    for pos in (len(z) // 3, len(z) // 2, len(z) - 40):                                                 # payload or trailer damaged
+        bad = bytearray(z)
+        bad[pos] ^= 0x5A
+        with pytest.raises(engine.EngineError):
+            engine.gunzip(bytes(bad), threads=4)
+    with pytest.raises(engine.EngineError):                                                             # cut inside a block
+        engine.gunzip(z[: len(z) // 2], threads=4)
