@@ -66,6 +66,21 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     const size_t slack = GzInflater::kOvershoot + 16;
     out.assign(std::max<size_t>(hint, 1u << 16) + slack, 0);
     size_t n = 0;
+    {   // bgzip output (assemblies kept indexable with faidx): the blocks side by side; what follows them, sequentially
+        BgzfReader bgzf;
+        if (bgzf.start(raw.data(), got, 8)) {
+            for (;;) {
+                if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2);
+                const size_t r = bgzf.read(out.data() + n, out.size() - slack - n);
+                if (r == (size_t)-1) return read_all_zlib(path, out);
+                if (r == 0) break;
+                n += r;
+            }
+            const size_t off = bgzf.consumed_input();
+            if (off >= got) { out.resize(n); return MHX_OK; }
+            inf.set_input(raw.data() + off, got - off);
+        }
+    }
     for (;;) {
         const size_t r = inf.inflate(out.data() + n, out.size() - slack - n, out.data());
         if (r == (size_t)-1) return read_all_zlib(path, out); // zlib has the last word on a stream this decoder refuses

@@ -112,3 +112,23 @@ def test_no_counted_record_is_an_error_on_both_paths(tmp_path, monkeypatch):
             monkeypatch.setenv("MHX_HOST_FASTA", "1")
         with pytest.raises(engine.NoRecordsError):
             engine.sketch_files([p], 21, 100, tmp_path / "x.msh")
+
+
+def test_bgzf_and_plain_gz_assemblies(tmp_path, monkeypatch):
+    """The same assembly plain, gzip'ed and bgzip'ed (BGZF blocks decoded side by side): one sketch, the oracle's."""
+    import gzip
+
+    from tests.test_lib_cpu import _bgzf
+
+    g = synth.make_genome(2_000_000, seed=9)
+    fa = synth.genome_fasta(g, n_contigs=7, width=80)
+    plain, gz, bg = tmp_path / "asm.fa", tmp_path / "asm.fa.gz", tmp_path / "asm.bgzf.fa.gz"
+    plain.write_bytes(fa)
+    gz.write_bytes(gzip.compress(fa, 6))
+    bg.write_bytes(_bgzf(fa, 6))
+    osk = _three_ways(tmp_path, [plain], 27, 5000, monkeypatch)
+    for p in (gz, bg):
+        engine.sketch_files([p], 27, 5000, tmp_path / "z.msh")
+        got = mo.read_msh(tmp_path / "z.msh").references[0]
+        assert np.array_equal(got.hashes, osk.references[0].hashes) and got.length == 2_000_000
+        assert got.comment == osk.references[0].comment

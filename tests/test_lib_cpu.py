@@ -351,3 +351,23 @@ def test_bgzf_blocks_are_decoded_side_by_side():
             engine.gunzip(bytes(bad), threads=4)
     with pytest.raises(engine.EngineError):                                                             # cut inside a block
         engine.gunzip(z[: len(z) // 2], threads=4)
+
+
+def test_fasta_reader_takes_bgzf(tmp_path):
+    """A bgzip'ed FASTA (kept indexable by faidx), with and without an ordinary member behind its blocks, through the
+    whole-file reader (mhx_fasta_total_bases; the FASTA sketch path reads files the same way)."""
+    import gzip
+
+    rng = np.random.default_rng(31)
+    seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1_300_000))
+    fa = b">c1 some contig\n" + b"\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + b"\n"
+    p = tmp_path / "a.fasta.gz"
+    p.write_bytes(_bgzf(fa, 6))
+    assert engine.fasta_total_bases(p) == len(seq)
+    p.write_bytes(_bgzf(fa, 6) + gzip.compress(b">c2\nACGTNACGT\n"))
+    assert engine.fasta_total_bases(p) == len(seq) + 9
+    bad = bytearray(_bgzf(fa, 6))
+    bad[len(bad) // 2] ^= 0x11
+    p.write_bytes(bytes(bad))
+    with pytest.raises(engine.EngineError):
+        engine.fasta_total_bases(p)
