@@ -54,7 +54,25 @@ hipError_t launch_phase_verify(const uint8_t *rec, uint32_t ntiles, uint64_t *st
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor = nullptr, uint32_t order_log2 = 0,
-                          uint64_t *hdr_dev = nullptr, uint64_t *hdr_host = nullptr, uint32_t *ticket = nullptr);
+                          uint64_t *hdr_dev = nullptr, uint64_t *hdr_host = nullptr, uint32_t *ticket = nullptr,
+                          uint64_t *occ_out = nullptr, uint32_t nhdr = 4);
+
+// sharded path: the other ranks' gathered partial results go into this rank's candidate table (slab_insert_kernel)
+constexpr uint32_t kMaxMergeRanks = 64; // ranks per launch (more: several launches)
+struct SlabMergeArgs {
+    const uint64_t *slabs;  // device: nranks slabs of slab_words 8-byte words each: hashes[cap] | counts u32[cap]
+    uint64_t slab_words, cap;
+    uint64_t n[kMaxMergeRanks]; // valid entries of each slab (0: skip)
+    uint32_t nranks, own_rank;  // own_rank: slab to skip (already in the table); >= nranks: none
+    uint64_t t_min;
+    uint64_t maxkey_others;     // occurrences of the hash value 2^64-1 on the other ranks
+    uint64_t *keys;
+    uint32_t *cnts;
+    uint64_t slot_mask;
+    uint64_t *thresh;
+    uint64_t *stats;
+};
+hipError_t launch_slab_insert(const SlabMergeArgs &a, uint64_t max_n, hipStream_t st);
 bool hash_k_supported(int k);
 
 // FASTA on the device (mhx_fasta.hip): raw file bytes -> dense sequence stream + record separator positions.

@@ -146,6 +146,14 @@ struct mhx_sketcher {
     uint32_t *d_out_cnts = nullptr;
     uint32_t *d_out_n = nullptr;
     uint32_t out_cap = 0;
+    // sharded path: header of the shard export [n, T, flags, #(2^64-1), occupied, 0, 0, 0], accumulated on the device and
+    // handed to the pinned mirror by the extract kernel itself (the entries stay in d_out_keys / d_out_cnts)
+    uint64_t *d_exp_hdr = nullptr, *h_exp_hdr = nullptr;
+    uint64_t exported = 0;     // entries of the last export_begin (valid until the next push / reset)
+    bool export_valid = false;
+    bool merged = false;       // merge_slabs has added other shards' entries to the table: reset before the next push
+    uint64_t *d_merge_in = nullptr; // staging of gathered slabs that arrive in host memory (gloo)
+    size_t merge_in_cap = 0;
     // finish(): one device block [n, T, flags, #(2^64-1) | hashes[fin_cap] | counts[fin_cap]] and its pinned host
     // mirror, so the result comes back in ONE copy (five separate copies cost 20-60 us of idle gap each)
     uint64_t *d_fin = nullptr, *h_fin = nullptr;
@@ -198,6 +206,8 @@ static void free_sketcher(mhx_sketcher *sk)
     hipFree(sk->d_keys); hipFree(sk->d_cnts); hipFree(sk->d_thresh); hipFree(sk->d_hist); hipFree(sk->d_acc);
     hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_need); hipFree(sk->d_phase_rec); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
     hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
+    hipFree(sk->d_exp_hdr); hipFree(sk->d_merge_in);
+    if (sk->h_exp_hdr) hipHostFree(sk->h_exp_hdr);
     hipFree(sk->d_fin);
     hipFree(sk->d_fin_ordered);
     hipFree(sk->d_order_buckets);
@@ -227,6 +237,8 @@ extern "C" int mhx_sketcher_reset(mhx_sketcher *sk)
     HIPCHK(launch_reset(table_args(sk), sk->t_init, sk->d_tickets, kTicketWords, sk->d_out_n, g.stream));
     sk->tickets_used = 0;
     sk->table_dirty = true;
+    sk->merged = false;
+    sk->export_valid = false;
     sk->unsettled.clear();
     sk->last_T = sk->hash_max;
     sk->bounded = false;
@@ -284,6 +296,9 @@ int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_byte
     A((void **)&sk->d_out_keys, sk->out_cap * sizeof(uint64_t));
     A((void **)&sk->d_out_cnts, sk->out_cap * sizeof(uint32_t));
     A((void **)&sk->d_out_n, sizeof(uint32_t));
+    A((void **)&sk->d_exp_hdr, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(sk->d_exp_hdr, 0, 8 * sizeof(uint64_t)); // zero between two exports (the kernel clears them)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sk->h_exp_hdr, 8 * sizeof(uint64_t), hipHostMallocDefault);
     sk->fin_cap = (s + 16u * (uint32_t)sqrt((double)s) + 4096u + 1u) & ~1u; // what a sampled threshold leaves, with room (finish())
     const size_t fin_bytes = (4 + (size_t)sk->fin_cap + sk->fin_cap / 2) * sizeof(uint64_t);
     A((void **)&sk->d_fin, fin_bytes);
@@ -380,7 +395,9 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     if (rc) return rc;
     if (!sk || (!d_bytes && n)) return fail(MHX_E_ARG, "null argument");
     if (fmt != MHX_FMT_SEQ && fmt != MHX_FMT_FASTQ4) return fail(MHX_E_ARG, "unknown stream format %d", fmt);
+    if (sk->merged) return fail(MHX_E_ARG, "this sketcher holds a merged (multi-shard) table: mhx_sketcher_reset() before the next push");
     if (n == 0) return MHX_OK;
+    sk->export_valid = false;
     if (fmt == MHX_FMT_SEQ) return push_span(sk, d_bytes, n, 0, false);
     static const bool no_selfsync = getenv("MHX_NO_SELFSYNC") != nullptr;
     if (no_selfsync) return push_span(sk, d_bytes, n, 1, false);
@@ -883,6 +900,177 @@ extern "C" int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t
     HIPCHK(launch_extract(table_args(sk), 0, 1, w + 3, (uint32_t *)(w + 3 + cap), cap, (uint32_t *)w, w + 2, sk->d_thresh, w + 1, nullptr, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
+}
+
+// ---- sharded path: sizes first, slabs sized from the data, merge on the device ------------------
+// 1. mhx_sketcher_export_begin : every (hash, count) <= T_r of this shard -> the sketcher's own device buffer; the
+//                                 header [n_r, T_r, flags, #(2^64-1), occupied slots] comes back (ranks all-gather it)
+// 2. mhx_sketcher_export_pack  : the entries as ONE slab [hashes[cap] | counts u32[cap]], cap = max_r n_r, into the
+//                                 caller's send buffer (device memory for RCCL, host memory for gloo)
+// 3. mhx_sketcher_merge_slabs  : the other ranks' gathered slabs are added to this rank's candidate table
+//                                 (slab_insert_kernel), the ordinary extraction with limit T_min = min_r T_r yields the
+//                                 union's sketch; same exactness rule as finish() -> MHX_E_CAPACITY, never a short sketch
+static int export_begin_impl(mhx_sketcher *sk, uint64_t *header8)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !header8) return fail(MHX_E_ARG, "null argument");
+    if (sk->merged) return fail(MHX_E_ARG, "this sketcher holds a merged table: mhx_sketcher_reset() first");
+    rc = settle(sk);
+    if (rc) return rc;
+    uint64_t *d = sk->d_exp_hdr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // one kernel: entries to d_out_keys / d_out_cnts, the five header words accumulated on the device and stored
+        // into the pinned mirror (and cleared for the next call) by the workgroup that finishes last
+        HIPCHK(launch_extract(table_args(sk), 0, 1, sk->d_out_keys, sk->d_out_cnts, sk->out_cap, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3,
+                              g.stream, nullptr, 0, d, sk->h_exp_hdr, sk->d_done, d + 4, 5));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        const uint64_t n = sk->h_exp_hdr[0];
+        if (n > sk->out_cap) { // grow (with room for the next, similar shard) and repeat once
+            hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts);
+            sk->d_out_keys = nullptr; sk->d_out_cnts = nullptr;
+            if (n + n / 4 + 1024 > 0xFFFFFFF0ull) return fail(MHX_E_CAPACITY, "export: %llu entries", (unsigned long long)n);
+            sk->out_cap = (uint32_t)(n + n / 4 + 1024);
+            HIPCHK(hipMalloc((void **)&sk->d_out_keys, (size_t)sk->out_cap * sizeof(uint64_t)));
+            HIPCHK(hipMalloc((void **)&sk->d_out_cnts, (size_t)sk->out_cap * sizeof(uint32_t)));
+            continue;
+        }
+        for (int i = 0; i < 5; ++i) header8[i] = sk->h_exp_hdr[i];
+        header8[5] = header8[6] = header8[7] = 0;
+        sk->exported = n;
+        sk->export_valid = true;
+        sk->last_T = header8[1];
+        return MHX_OK;
+    }
+    return fail(MHX_E_INTERNAL, "export: output kept growing");
+}
+
+extern "C" int mhx_sketcher_export_begin(mhx_sketcher *sk, uint64_t *header8)
+{
+    try {
+        return export_begin_impl(sk, header8);
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_export_begin: %s", e.what());
+    }
+}
+
+extern "C" int mhx_sketcher_export_pack(mhx_sketcher *sk, void *dst, uint64_t cap_entries)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !dst) return fail(MHX_E_ARG, "null argument");
+    if (!sk->export_valid) return fail(MHX_E_ARG, "export_pack without a preceding mhx_sketcher_export_begin");
+    if ((cap_entries & 1) || cap_entries < sk->exported) return fail(MHX_E_ARG, "export_pack: capacity %llu is odd or below this shard's %llu entries",
+                                                                     (unsigned long long)cap_entries, (unsigned long long)sk->exported);
+    uint8_t *p = (uint8_t *)dst;
+    if (sk->exported) { // device-to-device for RCCL send buffers, device-to-host for gloo's
+        HIPCHK(hipMemcpyAsync(p, sk->d_out_keys, sk->exported * sizeof(uint64_t), hipMemcpyDefault, g.stream));
+        HIPCHK(hipMemcpyAsync(p + cap_entries * sizeof(uint64_t), sk->d_out_cnts, sk->exported * sizeof(uint32_t), hipMemcpyDefault, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return MHX_OK;
+}
+
+static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_device, uint32_t n_ranks, uint64_t cap_entries,
+                            const uint64_t *headers, uint32_t own_rank, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !headers || !hashes || !n_out || n_ranks == 0) return fail(MHX_E_ARG, "null argument");
+    if (own_rank >= n_ranks) return fail(MHX_E_ARG, "own_rank %u out of range (%u ranks)", own_rank, n_ranks);
+    if (cap_entries & 1) return fail(MHX_E_ARG, "merge_slabs: odd slab capacity");
+    if (sk->merged) return fail(MHX_E_ARG, "this sketcher holds a merged table already: mhx_sketcher_reset() first");
+    if (!sk->export_valid) return fail(MHX_E_ARG, "merge_slabs without a preceding mhx_sketcher_export_begin on this sketcher");
+    uint64_t t_min = ~0ull, others = 0, maxkey_others = 0, flags = 0, max_n = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const uint64_t *h = headers + 8 * (size_t)r;
+        if (h[0] > cap_entries) return fail(MHX_E_ARG, "merge_slabs: rank %u announces %llu entries, slabs hold %llu", r, (unsigned long long)h[0], (unsigned long long)cap_entries);
+        t_min = h[1] < t_min ? h[1] : t_min;
+        flags |= h[2] & kFlagErrorMask & ~kFlagNeedLookback;
+        if (r != own_rank) { others += h[0]; maxkey_others += h[3]; max_n = h[0] > max_n ? h[0] : max_n; }
+    }
+    if (headers[8 * (size_t)own_rank] != sk->exported || headers[8 * (size_t)own_rank + 1] != sk->last_T)
+        return fail(MHX_E_ARG, "merge_slabs: header of rank %u is not this sketcher's export", own_rank);
+    rc = check_flags(flags); // a full table or a malformed FASTQ on ANY rank
+    if (rc) return rc;
+    if ((others || n_ranks > 1) && !slabs) return fail(MHX_E_ARG, "null slabs");
+    const uint64_t slab_words = cap_entries + cap_entries / 2;
+    const uint64_t occupied = headers[8 * (size_t)own_rank + 4];
+    if (occupied + others > sk->nslots / 2) {
+        // The other shards' entries would crowd this table (tiny tables of tiny inputs, or shards that never tightened
+        // their thresholds): the host merge decides instead, by the same rule on the same gathered data.
+        std::vector<uint64_t> hbuf((size_t)n_ranks * slab_words);
+        if (slabs_on_device) {
+            HIPCHK(hipMemcpyAsync(hbuf.data(), slabs, hbuf.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        } else {
+            memcpy(hbuf.data(), slabs, hbuf.size() * sizeof(uint64_t));
+        }
+        std::vector<uint64_t> ah, an(n_ranks), at(n_ranks);
+        std::vector<uint32_t> ac;
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            const uint64_t n = headers[8 * (size_t)r], mk = headers[8 * (size_t)r + 3];
+            const uint64_t *hp = hbuf.data() + (size_t)r * slab_words;
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(hp + cap_entries);
+            ah.insert(ah.end(), hp, hp + n);
+            ac.insert(ac.end(), cp, cp + n);
+            an[r] = n;
+            at[r] = headers[8 * (size_t)r + 1];
+            if (mk && at[r] == ~0ull) { ah.push_back(~0ull); ac.push_back(mk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mk); ++an[r]; } // the one value the table cannot hold
+        }
+        sk->merged = true;
+        return mhx_merge_shard_partials(ah.data(), ac.data(), an.data(), at.data(), n_ranks, sk->k, sk->s, sk->m, hashes, counts, n_out);
+    }
+    const uint64_t *d_slabs = (const uint64_t *)slabs;
+    if (!slabs_on_device && others) {
+        const size_t bytes = (size_t)n_ranks * slab_words * sizeof(uint64_t);
+        if (sk->merge_in_cap < bytes) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            hipFree(sk->d_merge_in);
+            sk->d_merge_in = nullptr;
+            sk->merge_in_cap = 0;
+            const size_t cap = (bytes + bytes / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+            HIPCHK(hipMalloc((void **)&sk->d_merge_in, cap));
+            sk->merge_in_cap = cap;
+        }
+        HIPCHK(hipMemcpyAsync(sk->d_merge_in, slabs, bytes, hipMemcpyHostToDevice, g.stream));
+        d_slabs = sk->d_merge_in;
+    }
+    sk->merged = true;
+    for (uint32_t r0 = 0; r0 < n_ranks; r0 += kMaxMergeRanks) { // (one launch for up to 64 ranks)
+        SlabMergeArgs a;
+        a.slabs = d_slabs + (size_t)r0 * slab_words;
+        a.slab_words = slab_words;
+        a.cap = cap_entries;
+        a.nranks = n_ranks - r0 < kMaxMergeRanks ? n_ranks - r0 : kMaxMergeRanks;
+        for (uint32_t r = 0; r < kMaxMergeRanks; ++r) a.n[r] = r < a.nranks ? headers[8 * (size_t)(r0 + r)] : 0;
+        a.own_rank = own_rank >= r0 && own_rank - r0 < a.nranks ? own_rank - r0 : kMaxMergeRanks;
+        a.t_min = t_min;
+        a.maxkey_others = r0 == 0 ? maxkey_others : 0;
+        a.keys = sk->d_keys; a.cnts = sk->d_cnts; a.slot_mask = sk->nslots - 1; a.thresh = sk->d_thresh; a.stats = sk->d_stats;
+        HIPCHK(launch_slab_insert(a, max_n, g.stream));
+    }
+    // the table now holds the union below T_min with summed counts, and T = T_min on the device: the ordinary extraction
+    // (count >= m, hash <= T, ordering kernels for large sketches) and finish()'s exactness rule do the rest
+    sk->table_dirty = false;
+    sk->table_sampled = false;
+    sk->unsettled.clear();
+    return mhx_sketcher_finish(sk, hashes, counts, n_out);
+}
+
+extern "C" int mhx_sketcher_merge_slabs(mhx_sketcher *sk, const void *slabs, int slabs_on_device, uint32_t n_ranks, uint64_t cap_entries,
+                                        const uint64_t *headers, uint32_t own_rank, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+{
+    try {
+        return merge_slabs_impl(sk, slabs, slabs_on_device, n_ranks, cap_entries, headers, own_rank, hashes, counts, n_out);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_slabs: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_slabs: %s", e.what());
+    }
 }
 
 // Union of shard partials: sum the counts of equal hashes, keep count >= m, first s.

@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
                                                             uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                                                             uint64_t *limit_out, uint64_t *maxkey_out,
                                                             uint32_t *order_cursor, uint32_t order_log2,
-                                                            uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket)
+                                                            uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket,
+                                                            uint64_t *occ_out, uint32_t nhdr)
 {
     if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
     const int bucket_shift = order_shift(limit, order_log2);
@@ -589,9 +590,10 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     constexpr uint32_t kBuf = 1024;
     __shared__ unsigned long long bkeys[kBuf];
     __shared__ uint32_t bcnts[kBuf];
-    __shared__ uint32_t nbuf, base;
-    if (threadIdx.x == 0) nbuf = 0;
+    __shared__ uint32_t nbuf, base, occ_s;
+    if (threadIdx.x == 0) { nbuf = 0; occ_s = 0; }
     __syncthreads();
+    uint32_t occ = 0; // occupied slots seen by this thread (reported when occ_out is given: the shard export)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (a.nslots + stride - 1) / stride; // same trip count for every thread (barriers inside)
     for (uint64_t rd = 0; rd <= rounds; ++rd) {
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
             const uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
             if (i < a.nslots) {
                 const uint64_t key = a.keys[i];
+                occ += key != kEmptyKey ? 1u : 0u;
                 if (key != kEmptyKey && key <= limit) {
                     const uint32_t c = a.cnts[i];
                     if (c >= min_count) {
@@ -630,6 +633,11 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     // no header memset in front of the kernel, no copy command behind it.  Same hand-over as the tighten pass: every
     // wave waits for its own memory operations, one lane releases and takes the ticket, the last workgroup reads the
     // words with agent-scope loads.
+    if (occ_out) { // table occupancy (the sharded merge sizes its insertions against it), one global atomic per workgroup
+        if (occ) atomicAdd(&occ_s, occ);
+        __syncthreads();
+        if (threadIdx.x == 0 && occ_s) atomicAdd(reinterpret_cast<unsigned long long *>(occ_out), (unsigned long long)occ_s);
+    }
     if (!hdr_host) return;
     __shared__ uint32_t last_s;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     }
     __syncthreads();
     if (!last_s) return;
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < nhdr) {
         const uint64_t v = __hip_atomic_load(&hdr_dev[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hdr_host[threadIdx.x] = v;
         __hip_atomic_store(&hdr_dev[threadIdx.x], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -651,13 +659,64 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor, uint32_t order_log2,
-                          uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket)
+                          uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket, uint64_t *occ_out, uint32_t nhdr)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
                        out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out, order_cursor, order_log2,
-                       hdr_dev, hdr_host, ticket);
+                       hdr_dev, hdr_host, ticket, occ_out, nhdr);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Sharded path, the merge where the data is (mhx_sketcher_merge_slabs): after the all-gather every
+// rank holds all ranks' partial results in HBM.  Its own entries already sit in its candidate table with exact
+// counts; the other ranks' entries <= T_min are added to that table -- a key is claimed by CAS (or found), its count
+// added atomically -- and the ordinary extraction (count >= m, hash <= T_min) then yields the union's sketch.
+// One thread per entry, ranks along grid.y; the gathered buffer is `nranks` slabs of `slab_words` 8-byte words:
+// hashes[cap], then the u32 counts.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_insert_kernel(const SlabMergeArgs a)
+{
+    const uint32_t r = blockIdx.y;
+    if (blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
+        *a.thresh = a.t_min; // what the extraction behind this kernel reads as its limit
+        if (a.maxkey_others) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + kStatMaxKey, (unsigned long long)a.maxkey_others);
+    }
+    if (r == a.own_rank) return;
+    const uint64_t n = a.n[r];
+    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(hashes + a.cap);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(a.keys);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = hashes[i];
+        if (h > a.t_min || h == kEmptyKey) continue; // above T_min a shard's list is incomplete: not part of the union's evidence
+        const uint32_t c = counts[i];
+        uint64_t slot = h & a.slot_mask;
+        bool placed = false;
+        for (int probe = 0; probe < 8192; ++probe) {
+            // a slot only ever goes from vacant to a key: a plain load that shows this hash (or another one) is final,
+            // one that shows a vacant slot is settled by the CAS
+            unsigned long long cur = keys[slot];
+            if (cur == kEmptyKey) cur = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)h);
+            if (cur == kEmptyKey || cur == h) {
+                atomicAdd(&a.cnts[slot], c);
+                placed = true;
+                break;
+            }
+            slot = (slot + 1) & a.slot_mask;
+        }
+        if (!placed) atomicOr(reinterpret_cast<unsigned long long *>(a.stats) + kStatFlags, (unsigned long long)kFlagTableFull);
+    }
+}
+
+hipError_t launch_slab_insert(const SlabMergeArgs &a, uint64_t max_n, hipStream_t st)
+{
+    uint64_t blocks = (max_n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(slab_insert_kernel, dim3((unsigned)blocks, a.nranks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

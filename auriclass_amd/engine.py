@@ -110,6 +110,10 @@ def load() -> ctypes.CDLL:
     L.mhx_msh_write.argtypes = [c.c_char_p, c.c_int, c.c_uint32, c.c_uint32, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                 u64p, c.POINTER(u64p), u32p]
     L.mhx_sketcher_export_slab.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32]
+    L.mhx_sketcher_export_begin.argtypes = [c.c_void_p, c.c_void_p]
+    L.mhx_sketcher_export_pack.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64]
+    L.mhx_sketcher_merge_slabs.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_uint32, c.c_uint64, c.c_void_p, c.c_uint32,
+                                           c.c_void_p, c.c_void_p, u32p]
     L.mhx_gunzip_buffer.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t)]
     L.mhx_gunzip_buffer_mt.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_int]
     _lib = L
@@ -288,6 +292,32 @@ class Sketcher:
         """Partial result as one device-resident int64 slab [n, T, flags, hashes[cap], counts (u32 pairs)];
         `device_ptr` must hold 3 + cap + cap // 2 int64 words (see include/mhx.h)."""
         _check(load().mhx_sketcher_export_slab(self._h, ctypes.c_void_p(device_ptr), cap))
+
+    def export_begin(self) -> np.ndarray:
+        """Sharded path, step 1: compacts this shard's partial result (every (hash, count) <= its threshold) on the
+        device and returns the 8-word header [n, T, flags, #(2^64-1), occupied slots, 0, 0, 0] the ranks exchange."""
+        hdr = np.zeros(8, dtype=np.uint64)
+        _check(load().mhx_sketcher_export_begin(self._h, hdr.ctypes.data))
+        return hdr
+
+    def export_pack(self, dst_ptr: int, cap_entries: int) -> None:
+        """Step 2: the partial result as one slab [hashes[cap_entries] | counts u32[cap_entries]] at `dst_ptr`
+        (device or host memory; cap_entries + cap_entries // 2 eight-byte words)."""
+        _check(load().mhx_sketcher_export_pack(self._h, ctypes.c_void_p(dst_ptr), cap_entries))
+
+    def merge_slabs(self, slabs_ptr: int, on_device: bool, n_ranks: int, cap_entries: int, headers: np.ndarray, own_rank: int
+                    ) -> Tuple[np.ndarray, np.ndarray]:
+        """Step 3: adds the other ranks' gathered slabs to this sketcher's table ON THE DEVICE and extracts the sketch of
+        the union (EngineError(MHX_E_CAPACITY) when the partials do not determine it).  The sketcher must be reset()
+        before it is pushed to again."""
+        headers = np.ascontiguousarray(headers, dtype=np.uint64).reshape(-1)
+        assert headers.size == 8 * n_ranks
+        hashes = np.zeros(self.s, dtype=np.uint64)
+        counts = np.zeros(self.s, dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        _check(load().mhx_sketcher_merge_slabs(self._h, ctypes.c_void_p(slabs_ptr), int(on_device), n_ranks, cap_entries,
+                                               headers.ctypes.data, own_rank, hashes.ctypes.data, counts.ctypes.data, ctypes.byref(n)))
+        return hashes[:n.value].copy(), counts[:n.value].copy()
 
     def export(self, limit: int) -> Tuple[np.ndarray, np.ndarray]:
         cap = 1 << 16

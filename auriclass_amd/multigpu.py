@@ -4,9 +4,12 @@ record-aligned shard, then ONE collective merges the partial results (SURVEY.md 
 
   1. every rank exports all (hash, count) it saw with hash <= its own admission threshold T_r
      (no multiplicity filter, so counts stay summable)
-  2. ONE all-gather of a fixed-size slab per rank: [n, T_r, flags, hashes.., counts..]
-  3. every rank takes T_min = min_r T_r, drops what lies above it, and merges: sum counts per hash,
-     keep count >= m, first s ascending (engine.merge_shard_partials = mhx_merge_shard_partials).
+  2. sizes first (an all-gather of 64-byte headers: n_r, T_r, flags), then ONE all-gather of slabs sized
+     from the data: [hashes[max n_r] | counts]
+  3. every rank takes T_min = min_r T_r, drops what lies above it, and merges ON THE DEVICE: the other
+     ranks' entries are added to its own candidate table (sum of counts per hash), the ordinary extraction
+     keeps count >= m, first s ascending (exchange_and_merge_device / mhx_sketcher_merge_slabs; the host
+     form exchange_and_merge / mhx_merge_shard_partials serves the CPU tests of the decision logic).
   4. the exactness rule, on gathered data only, so that every rank reaches the same verdict:
      >= s merged entries qualify below T_min, or no rank has ever rejected a hash (T_min is still
      the largest hash value) -> done; otherwise :class:`InexactShardedSketch` -- never a short sketch.
@@ -18,8 +21,9 @@ qualify globally too, so the union has its s entries below T_min.  With a multip
 (m > 1; 3 is AuriClass's FASTQ default, /root/reference/auriclass/args.py:128-134) a shard's threshold
 is at first a host-imposed CAP that follows the bytes seen (mhx_engine.cpp, push_device); a shallow
 shard can end with that cap below the global s-th solid hash -- plenty of solid k-mers exist, but above
-T_min, where the other ranks' lists are incomplete.  The payload is a few thousand 12-byte entries per
-rank: latency-bound, not link-bound, which is why it is a single collective.
+T_min, where the other ranks' lists are incomplete.  The payload is ~1.1 s entries of 12 bytes per rank for
+m = 1 and ~10-14 s entries for m = 3 on error-bearing reads (every singleton below T_r travels, counts
+must stay summable): 13 KB ... 8 MB per rank, still latency- rather than link-bound on xGMI.
 """
 from __future__ import annotations
 
@@ -100,30 +104,79 @@ def exchange_and_merge(local_threshold: int, export: Callable[[int], Tuple[np.nd
     return _merge(all_h, all_c, thresholds, k, s, min_mult)
 
 
+# timings of the last exchange_and_merge_device call on this rank (ms) and its payload: bench.py reports them
+last_exchange: dict = {}
+_buffers: dict = {}
+
+
+def _buffer(tag: str, numel: int, device: torch.device) -> torch.Tensor:
+    """Send / receive buffers are kept between calls (a fresh 66 MB host tensor costs more than the collective)."""
+    key = (tag, str(device))
+    t = _buffers.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.empty(numel + numel // 4, dtype=torch.int64, device=device)
+        _buffers[key] = t
+    return t[:numel]
+
+
+def _all_gather_flat(out: torch.Tensor, t: torch.Tensor) -> None:
+    try:
+        dist.all_gather_into_tensor(out, t)
+    except (RuntimeError, NotImplementedError, AttributeError):   # backend without the flat form
+        world = dist.get_world_size()
+        parts = [out[r * t.numel():(r + 1) * t.numel()] for r in range(world)]
+        dist.all_gather(parts, t)
+
+
 def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.ndarray]:
-    """The same exchange with the partial results staying on the GPU until they have been gathered:
-    `sk.export_slab` writes [n, T_r, flags, hashes.., counts..] into a device tensor (one kernel, no
-    PCIe), the slabs are all-gathered by RCCL, ONE device-to-host copy brings all of them over, and the
-    merge runs on the host as before.  Falls back to exchange_and_merge (on every rank alike, the decision
-    only uses gathered data) when a slab overflowed or a 64-bit shard never tightened its threshold
-    (the hash value 2^64-1 has no place in a slab).  Same exactness rule, same exception."""
-    k, s, min_mult = sk.k, sk.s, sk.m
-    cap = 4 * s + 4096
-    slab = torch.empty(3 + cap + cap // 2, dtype=torch.int64, device=device)
-    sk.export_slab(slab.data_ptr(), cap)
-    got = _gather(slab)
-    sizes = [int(g[0]) for g in got]
-    thresholds = [int(g[1:2].view(np.uint64)[0]) for g in got]
+    """The exchange as SURVEY.md 8(e) lays it out, with the merge where the data is:
+      1. `sk.export_begin()` compacts the shard's partial result on the GPU; the ranks all-gather the 64-byte headers
+         (n_r, T_r, flags, count of the hash value 2^64-1, table occupancy) -- sizes first;
+      2. ONE all-gather of slabs sized from the data (max_r n_r entries, rounded up to 1024): RCCL moves them from HBM
+         to HBM over xGMI (`device` cuda), gloo through host memory (`device` cpu, the rehearsal / test form);
+      3. `sk.merge_slabs` adds the other ranks' entries <= T_min to this rank's candidate table with device atomics and
+         runs the ordinary extraction: nothing is sorted or merged on the host, whatever m and s are.
+    Same exactness rule as finish(), decided from gathered data only, so every rank raises InexactShardedSketch
+    together.  The sketcher's table holds the union afterwards: reset() it before the next push."""
+    import time
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_device = device.type == "cuda"
+    t0 = time.perf_counter()
+    hdr = sk.export_begin()
+    t1 = time.perf_counter()
+    mine = torch.from_numpy(hdr.view(np.int64)).to(device)
+    all_hdr_t = torch.empty(world * 8, dtype=torch.int64, device=device)
+    _all_gather_flat(all_hdr_t, mine)
+    all_hdr = all_hdr_t.cpu().numpy().view(np.uint64).reshape(world, 8)
+    t2 = time.perf_counter()
     flags = 0
-    for g in got:
-        flags |= int(g[2]) & DEVICE_FLAG_MASK
+    for r in range(world):
+        flags |= int(all_hdr[r, 2]) & DEVICE_FLAG_MASK & ~0x8
     if flags:
         raise RuntimeError(f"device flags {flags:#x} raised during sketching (table full / malformed FASTQ)")
-    if max(sizes) > cap or max(thresholds) == U64_MAX:
-        return exchange_and_merge(sk.threshold(), sk.export, k, s, min_mult, device)
-    all_h = [g[3:3 + sizes[r]].view(np.uint64) for r, g in enumerate(got)]
-    all_c = [g[3 + cap:].view(np.uint32)[:sizes[r]] for r, g in enumerate(got)]
-    return _merge(all_h, all_c, thresholds, k, s, min_mult)
+    max_n = int(all_hdr[:, 0].max())
+    cap = max(1024, (max_n + 1023) // 1024 * 1024)
+    words = cap + cap // 2
+    send = _buffer("send", words, device)
+    sk.export_pack(send.data_ptr(), cap)
+    t3 = time.perf_counter()
+    recv = _buffer("recv", world * words, device)
+    _all_gather_flat(recv, send)
+    if on_device:
+        torch.cuda.current_stream(device).synchronize()   # the merge runs on the engine's own stream
+    t4 = time.perf_counter()
+    try:
+        result = sk.merge_slabs(recv.data_ptr(), on_device, world, cap, all_hdr, rank)
+    except engine.EngineError as e:
+        if e.code == engine.MHX_E_CAPACITY:
+            raise InexactShardedSketch(e.code, e.message) from None
+        raise
+    t5 = time.perf_counter()
+    last_exchange.update(export_ms=(t1 - t0) * 1e3, sizes_ms=(t2 - t1) * 1e3, pack_ms=(t3 - t2) * 1e3, gather_ms=(t4 - t3) * 1e3,
+                         merge_ms=(t5 - t4) * 1e3, total_ms=(t5 - t0) * 1e3, entries_per_rank=[int(x) for x in all_hdr[:, 0]],
+                         slab_bytes=words * 8)
+    return result
 
 
 def sharded_sketch(push: Callable[[object], None], k: int, s: int, min_mult: int, expected_bytes: int, device: torch.device,
@@ -145,7 +198,7 @@ def sharded_sketch(push: Callable[[object], None], k: int, s: int, min_mult: int
             own = True
             push(sk)
         try:
-            if device.type == "cuda":
+            if hasattr(sk, "export_begin"):   # the engine's sketcher: partials merged on the GPU (RCCL or gloo transport)
                 return exchange_and_merge_device(sk, device)
             return exchange_and_merge(sk.threshold(), sk.export, k, s, min_mult, device)
         except InexactShardedSketch:

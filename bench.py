@@ -116,7 +116,10 @@ def main() -> None:
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
     ap.add_argument("--cpu-cores", type=int, default=0,
                     help="host cores of the CPU leg; 0 = min(cores this process may run on, 16 = the CPU share of a 1-GPU box)")
+    ap.add_argument("--cpu-single-reads", type=int, default=500_000, help="reads of the one-process CPU figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-sketch", default="", help="rank 0 saves the final sketch (hashes, counts) to this .npz")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the sharded == unsharded check (rank 0 re-sketches all shards)")
     args = ap.parse_args()
 
     nproc = os.cpu_count() or 1
@@ -206,9 +209,14 @@ def main() -> None:
     for _ in range(args.warmup):
         result = step()
     barrier()
+    exch = {}   # this rank's time inside the exchange (export, size all-gather, pack, slab all-gather, device merge), summed
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = step()
+        if use_dist:
+            for key, v in multigpu.last_exchange.items():
+                if key.endswith("_ms"):
+                    exch[key] = exch.get(key, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -228,6 +236,7 @@ def main() -> None:
     roofline = None
     cpu_baseline = None
     parity = None
+    parity_kind = None
     if rank == 0:
         engine.set_profiling(True)
         ms = []
@@ -244,6 +253,7 @@ def main() -> None:
         # workload they were collected on
         traffic = None
         valu_instr = None
+        clock_ghz = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
@@ -251,33 +261,67 @@ def main() -> None:
                 if tj.get("algorithmic_bytes_per_step") == nbytes and (args.k, args.s, args.m) == (21, 1000, 1):
                     traffic = tj.get("sketch_tile_kernel_hbm_bytes_per_step")
                     valu_instr = tj.get("sketch_tile_kernel_valu_wave_instructions_per_step")
+                    clock_ghz = tj.get("shader_clock_ghz_from_pmc")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "sketch_tile_kernel", "kernel_ms_per_step": round(kernel_ms, 4),
                     "launches_per_step": st["launches"], "algorithmic_bytes_per_step": nbytes,
-                    "kmers_per_s": round(st["kmers"] / (kernel_ms / 1e3) / 1e9, 3), "kmers_unit": "G k-mers/s"}
-        if valu_instr:
+                    "kmers_per_s": round(st["kmers"] / (kernel_ms / 1e3) / 1e9, 3), "kmers_unit": "G k-mers/s",
+                    # achieved / frac / kernel_ms_per_step are measured in THIS run (HIP events on the engine stream);
+                    # traffic is a counter reading of an earlier profiling run of the same workload, quoted from a file
+                    "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc passes (tools/profile.sh) of this exact workload, "
+                                       "not of this run" if traffic else None)}
+        if valu_instr and clock_ghz:
             # the operative limit: wave64 integer VALU instructions issue at ~4 cycles each per SIMD;
-            # instruction count from the PMC pass of the same workload, time measured live, clock taken as 2.4 GHz
+            # instruction count and shader clock from the PMC passes of the same workload, time measured live
             simds = 256 * 4
             roofline["valu_issue"] = {"wave_instructions_per_step": valu_instr,
-                                      "cycles_per_instruction_per_simd": round(kernel_ms * 1e-3 * 2.4e9 * simds / valu_instr, 3),
-                                      "issue_cost_cycles": 4.0, "clock_ghz_assumed": 2.4}
+                                      "cycles_per_instruction_per_simd": round(kernel_ms * 1e-3 * clock_ghz * 1e9 * simds / valu_instr, 3),
+                                      "issue_cost_cycles": 4.0, "clock_ghz": clock_ghz,
+                                      "source": "profiles/traffic.json (SQ_INSTS_VALU and GRBM_GUI_ACTIVE of the PMC passes), not this run"}
+
+        # ---- N > 1: the gate of the sharded line.  Rank 0 sketches EVERY rank's shard (regenerated from the seeds) through
+        # one sketcher on its own GPU -- the oracle-pinned single-GPU path -- and compares with the merged result
+        if world > 1 and not args.no_parity:
+            skp = engine.Sketcher(args.k, args.s, args.m, expected_bytes=nbytes * world)
+            for r in range(world):
+                if r == rank:
+                    shard = fq
+                elif strong:
+                    lo_r, hi_r = multigpu.shard_bounds(args.total_reads, world, r)
+                    shard = synth.make_fastq_range(genome, lo_r, hi_r, args.read_len, device=str(dev))
+                else:
+                    shard = synth.make_fastq(genome, args.reads, args.read_len, seed=43 + r, device=str(dev), first_index=r * args.reads)
+                torch.cuda.synchronize()
+                skp.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+                skp.sync()   # the shard's buffer may go once the sketcher has settled
+                del shard
+            want_h, want_c = skp.finish()
+            skp.close()
+            parity = bool(np.array_equal(result[0], want_h) and np.array_equal(result[1], want_c))
+            parity_kind = (f"sharded sketch over {world} ranks == one sketcher over all {world} shards on rank 0's GPU "
+                           "(hashes and multiplicities); that single-GPU path is the one pinned against the CPU oracle at N=1")
 
         # ---- CPU baseline + parity on a bounded sample of the same workload -------------------
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is an N=1 figure; at N>1 every rank's host cores are busy
             n_s = min(args.cpu_sample_reads, args.reads)
             rb = synth.record_bytes(args.read_len)
             sample = fq[: n_s * rb].cpu().numpy()
+            # BASELINE.md section 3 / docs/running_analysis.md:47-59 of the reference: one process, and N processes (N stated)
+            n_1 = min(n_s, args.cpu_single_reads)
+            _, cpu_1, _ = cpu_baseline_run(sample[: n_1 * rb], rb, args.k, args.s, args.m, 1)
             want, cpu_s, cores = cpu_baseline_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
             cpu_baseline = {"value": round(n_s * args.read_len / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": cores,
                             "nproc": nproc, "usable_cores": usable,
                             "per_core": round(n_s * args.read_len / cpu_s / 1e9 / max(1, cores), 5),
                             "kind": "port",
+                            "one_process": {"value": round(n_1 * args.read_len / cpu_1 / 1e9, 5), "unit": "Gbases/s", "cores": 1,
+                                            "sample": f"first {n_1} reads, one process; wall {cpu_1:.1f} s"},
                             "sample": f"first {n_s} reads ({n_s * args.read_len / 1e6:.0f} Mbases) of rank 0's input in {cores} record "
-                                      f"shards, one process each: parse + sketch by the C oracle (oracle/mashcore.c), partial "
+                                      f"shards, one process each (N = {cores}: the CPU share of a 1-GPU box of this pool; the host shows "
+                                      f"{nproc} cores): parse + sketch by the C oracle (oracle/mashcore.c), partial "
                                       f"sketches merged; wall {cpu_s:.1f} s"}
             stock = stock_mash_run(sample, rb, args.k, args.s, args.m, args.cpu_cores)
             if stock is not None:   # a real mash on this host: that is the baseline to quote
@@ -291,6 +335,7 @@ def main() -> None:
             got, _ = sk2.finish()
             sk2.close()
             parity = bool(np.array_equal(got, want))
+            parity_kind = f"GPU sketch of the first {n_s} reads == C oracle ({cores} record shards merged), bit for bit"
 
     if rank == 0:
         line = {
@@ -304,10 +349,16 @@ def main() -> None:
                                     f"{args.genome} bp genome, 0.5% substitutions, {nbytes} bytes resident in HBM"),
                        "k": args.k, "s": args.s, "min_multiplicity": args.m, "total_bases": total_bases,
                        "ranks": ranks_in_group, "collective": (backend if use_dist else None),
+                       # rank 0's mean time per step inside the exchange: shard export, 64-byte size all-gather, slab pack,
+                       # slab all-gather, merge of the other ranks' entries into its table + extraction (all on the device)
+                       "exchange_ms": ({key: round(v / args.steps, 4) for key, v in sorted(exch.items())} if exch else None),
+                       "exchange_entries_per_rank": (multigpu.last_exchange.get("entries_per_rank") if use_dist else None),
                        "parallelism": "1 process/GPU, record shards, all-gather of partial sketches" if world > 1 else "1 GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            "parity_on_sample": parity, "sketch_len": int(len(result[0])),
+            "parity_on_sample": parity, "parity_kind": parity_kind, "sketch_len": int(len(result[0])),
         }
+    if rank == 0 and args.dump_sketch:
+        np.savez(args.dump_sketch, hashes=result[0], counts=result[1])
     sk.close()
     if use_dist:
         dist.destroy_process_group()

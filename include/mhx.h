@@ -133,6 +133,27 @@ int mhx_sketcher_export(mhx_sketcher *sk, uint64_t limit, uint64_t *hashes, uint
  * no multiplicity filter.  cap must be even.  The hash value 2^64-1 is not representable here: callers
  * fall back to mhx_sketcher_export when a threshold of 2^64-1 comes back. */
 int mhx_sketcher_export_slab(mhx_sketcher *sk, void *d_slab, uint32_t cap);
+/* The sharded path as the ranks run it (auriclass_amd/multigpu.py; SURVEY.md 8(e): sizes first, slabs sized from the
+ * data, merge where the data is).  Replaces nothing in the reference by itself: it is how `mash sketch -r -m M` over ONE
+ * sample (auriclass/classes.py:576-596) is spread over the GPUs of a node.
+ *   1. mhx_sketcher_export_begin: every (hash, count) of this shard with hash <= its threshold T_r (no multiplicity
+ *      filter) is compacted into a device buffer of the sketcher; header8 receives [0] n_r, [1] T_r, [2] device flags |
+ *      MHX_SLAB_* bits, [3] occurrences of the hash value 2^64-1, [4] occupied table slots, [5..7] 0.  Ranks all-gather
+ *      these 64 bytes.
+ *   2. mhx_sketcher_export_pack: the entries as one slab of 8-byte words, hashes[cap_entries] then the u32 counts
+ *      (cap_entries even, >= n_r; normally max_r n_r rounded up), written to dst -- device memory (RCCL send buffer) or
+ *      host memory (gloo).  Entries beyond n_r are unspecified.  Ranks all-gather the slabs.
+ *   3. mhx_sketcher_merge_slabs: slabs = the n_ranks gathered slabs back to back (slabs_on_device != 0: device
+ *      memory), headers = the n_ranks gathered headers (8 words each).  The other ranks' entries <= T_min = min_r T_r
+ *      are added to this rank's candidate table on the device and the union's sketch is extracted: the first s hashes
+ *      with summed multiplicity >= min_mult.  MHX_E_CAPACITY if fewer than s qualify below a lowered T_min (every rank
+ *      gets the same verdict from the same gathered data and sketches its shard again with a larger budget_scale).
+ *      The sketcher's table now holds other shards' entries: mhx_sketcher_reset() before it is used again. */
+int mhx_sketcher_export_begin(mhx_sketcher *sk, uint64_t *header8);
+int mhx_sketcher_export_pack(mhx_sketcher *sk, void *dst, uint64_t cap_entries);
+int mhx_sketcher_merge_slabs(mhx_sketcher *sk, const void *slabs, int slabs_on_device, uint32_t n_ranks,
+                             uint64_t cap_entries, const uint64_t *headers, uint32_t own_rank, uint64_t *hashes,
+                             uint32_t *counts, uint32_t *n_out);
 int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s,
                        uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
 /* bits a shard adds to word [2] of its slab besides the device flags (diagnostics of the m > 1 phase) */

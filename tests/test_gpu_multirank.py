@@ -29,7 +29,20 @@ def _input(n_reads):
     return synth.make_fastq(genome, n_reads, READ_LEN, seed=22, device="cpu").numpy()
 
 
-def _worker(rank, world, port, k, s, m, n_reads, out_dir):
+def _seqs(fq_bytes):
+    """sequence lines of a 4-line FASTQ (for the definition-level oracle)"""
+    return fq_bytes.split(b"\n")[1::4]
+
+
+def _exchange(sk, form, k, s, m):
+    """`device`: sizes first, data-sized slabs, merge on the GPU (gloo only carries the bytes); `host`: the
+    callback form with the host merge (what the CPU tests of the decision logic run)."""
+    if form == "device":
+        return multigpu.exchange_and_merge_device(sk, torch.device("cpu"))
+    return multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
+
+
+def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -46,27 +59,56 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir):
     sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
     sk.sync()
     assert sk.record_count() == hi - lo
-    got_h, got_c = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
+    got_h, got_c = _exchange(sk, form, k, s, m)
     np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
+    if form == "device":
+        np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array(multigpu.last_exchange["entries_per_rank"]))
+        # the table now holds the union: pushing without a reset must be refused, after a reset the sketcher is as new
+        with pytest.raises(engine.EngineError):
+            sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+        sk.reset()
+        sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+        again_h, again_c = _exchange(sk, form, k, s, m)
+        assert np.array_equal(again_h, got_h) and np.array_equal(again_c, got_c)
     sk.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,s,m", [(2, 21, 1000, 1), (2, 21, 1000, 3), (3, 27, 5000, 2)])
-def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, s, m):
+@pytest.mark.parametrize("form", ["device", "host"])
+@pytest.mark.parametrize("world,k,s,m", [(2, 21, 1000, 1), (2, 21, 1000, 3), (3, 27, 5000, 2), (3, 16, 3000, 2)])
+def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, s, m, form):
     from oracle import mash_oracle as mo
 
     n_reads = 60_000
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, k, s, m, n_reads, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, k, s, m, n_reads, str(tmp_path), form), nprocs=world, join=True)
     ref = mo.Sketcher(k, s, m)
     ref.add_fastx(_input(n_reads).tobytes())
-    want, want_counts = ref.finish()
+    want, _ = ref.finish()
     assert len(want) == s
+    # multiplicities: the engine's are exact; the definition-level oracle counts every window (mash's heap under-counts
+    # repeats of its current maximum)
+    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_input(n_reads).tobytes()), k, s, m)
+    assert np.array_equal(bf_h, want)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
-        assert np.load(tmp_path / f"c{r}.npy").min() >= m
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), bf_c), f"rank {r}: summed multiplicities"
+
+
+def test_exchange_whose_shards_exceed_a_fixed_slab(tmp_path):
+    """Error-bearing reads with a multiplicity filter: a shard exports every singleton below its threshold, far more
+    than the 4*s + 4096 entries of the fixed slab that rounds 1-2 gathered first (with AuriClass's defaults that
+    fixed slab ALWAYS overflowed).  The slabs are sized from the exchanged headers instead."""
+    from oracle import mash_oracle as mo
+
+    world, k, s, m, n_reads = 2, 21, 200, 3, 60_000
+    mp.spawn(_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path), "device"), nprocs=world, join=True)
+    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_input(n_reads).tobytes()), k, s, m)
+    for r in range(world):
+        assert max(np.load(tmp_path / f"n{r}.npy")) > 4 * s + 4096
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), bf_h)
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), bf_c)
 
 
 def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
@@ -82,19 +124,19 @@ def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
     torch.cuda.synchronize()
     sk = engine.Sketcher(k, s, m, expected_bytes=fq.numel())
     sk.push_device(fq.data_ptr(), fq.numel(), engine.FMT_FASTQ4)
-    got_h, got_c = multigpu.exchange_and_merge_device(sk, torch.device("cuda", 0))
     ref_h, ref_c = sk.finish()
+    got_h, got_c = multigpu.exchange_and_merge_device(sk, torch.device("cuda", 0))
     np.save(os.path.join(out_dir, "slab_h.npy"), got_h)
     np.save(os.path.join(out_dir, "slab_c.npy"), got_c)
     np.save(os.path.join(out_dir, "fin_h.npy"), ref_h)
     np.save(os.path.join(out_dir, "fin_c.npy"), ref_c)
-    # a tiny shard never tightens its threshold: every rank takes the host-side exchange instead
+    # a tiny shard never tightens its threshold (T stays at 2^64-1, a short sketch is the exact answer)
     sk2 = engine.Sketcher(k, s, m, expected_bytes=0)
     rb = synth.record_bytes(READ_LEN)
     sk2.push_device(fq.data_ptr(), 5 * rb, engine.FMT_FASTQ4)
-    tiny_h, _ = multigpu.exchange_and_merge_device(sk2, torch.device("cuda", 0))
     want_h, _ = sk2.finish()
-    assert np.array_equal(tiny_h, want_h)
+    tiny_h, _ = multigpu.exchange_and_merge_device(sk2, torch.device("cuda", 0))
+    assert np.array_equal(tiny_h, want_h) and 0 < len(tiny_h) < s
     sk.close()
     sk2.close()
     dist.destroy_process_group()
@@ -142,7 +184,7 @@ def _byte_range_worker(rank, world, port, k, s, m, out_dir):
     torch.cuda.synchronize()
     sk = engine.Sketcher(k, s, m, expected_bytes=shard.numel())
     sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
-    got_h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
+    got_h, _ = multigpu.exchange_and_merge_device(sk, torch.device("cpu"))
     np.save(os.path.join(out_dir, f"b{rank}.npy"), got_h)
     sk.close()
     dist.destroy_process_group()
@@ -204,7 +246,7 @@ def _hard_worker(rank, world, port, name, out_dir):
     sk = engine.Sketcher(k, s, m, expected_bytes=shard.numel())
     push(sk)
     try:
-        h, _ = multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
+        h, _ = multigpu.exchange_and_merge_device(sk, torch.device("cpu"))
         np.save(os.path.join(out_dir, f"plain{rank}.npy"), h)
     except multigpu.InexactShardedSketch:
         np.save(os.path.join(out_dir, f"plain{rank}.npy"), np.zeros(1, np.float64))   # marker: refused
@@ -231,6 +273,8 @@ def test_sharded_sketch_is_exact_or_refused_never_short(tmp_path, name, world):
         assert 0 < len(want) < s
     else:
         assert len(want) == s
+    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_hard_input(name).tobytes()), k, s, m)   # exact multiplicities
+    assert np.array_equal(bf_h, want)
     refused = []
     for r in range(world):
         plain = np.load(tmp_path / f"plain{r}.npy")
@@ -238,9 +282,9 @@ def test_sharded_sketch_is_exact_or_refused_never_short(tmp_path, name, world):
         if not refused[-1]:
             assert np.array_equal(plain, want), f"rank {r}: the bare exchange returned a sketch that is not the oracle's"
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
-        # counts: the engine's are exact multiplicities; the oracle reproduces mash's heap, which under-counts repeats
-        # of its current maximum, so only the filter itself is checked here
-        assert np.load(tmp_path / f"c{r}.npy").min() >= m, f"rank {r}"
+        # counts: the engine's are exact multiplicities (the oracle's heap reproduces mash's order-dependent
+        # under-count), so they are compared with the definition-level count of every window
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), bf_c), f"rank {r}: summed multiplicities"
     assert len(set(refused)) == 1, "ranks disagree on the verdict"
     attempts = {int(np.load(tmp_path / f"a{r}.npy")[0]) for r in range(world)}
     assert len(attempts) == 1, "ranks retried a different number of times"
