@@ -401,6 +401,10 @@ extern "C" int mhx_sketcher_push_device(mhx_sketcher *sk, const void *d_bytes, u
     if (fmt == MHX_FMT_SEQ) return push_span(sk, d_bytes, n, 0, false);
     static const bool no_selfsync = getenv("MHX_NO_SELFSYNC") != nullptr;
     if (no_selfsync) return push_span(sk, d_bytes, n, 1, false);
+    if (sk->unsettled.size() >= 4096) { // thousands of small pushes without a synchronisation point: settle what there is
+        rc = settle(sk);
+        if (rc) return rc;
+    }
     rc = push_span(sk, d_bytes, n, 2, false);
     if (!rc) sk->unsettled.push_back({d_bytes, n});
     return rc;
@@ -509,11 +513,14 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
         // the k-mers seen so far, ~0.4 per FASTQ byte: above ~3 candidates in 10^4 windows the queue wins); the very first
         // launch, which admits everything, and the long launches of a small sketch finish them where they are found.
         if (!force_queue) {
-            long double expected_rate = bytes_pushed ? (long double)sk->s / (0.4L * (long double)bytes_pushed) : 0.0L;
+            // (nothing pushed yet: T is still at its initial value and admits everything)
+            long double expected_rate = bytes_pushed ? std::min(1.0L, (long double)sk->s / (0.4L * (long double)bytes_pushed)) : 1.0L;
             // staged phase of the multiplicity filter: the threshold sits at the byte-count cap until solid hashes take over
             if (cur.cap) expected_rate = std::max(expected_rate, (long double)cur.cap / (long double)sk->hash_max);
-            // (a sequence stream fills the work list -- every group of a tile is an item --, which leaves the queue no room)
-            a.queue_candidates = (uint32_t)(kfmt != 0 && (sk->s >= kDeviceOrderMinSketch || (bytes_pushed && expected_rate > 3e-4L)));
+            // (a sequence stream fills the work list -- every group of a tile is an item --, which leaves the queue no room;
+            // above ~0.15 candidates per window the ~1100 free entries of a FASTQ tile's list overflow and the tile would do
+            // its work twice, see sketch_tile_kernel: such launches finish their candidates inline)
+            a.queue_candidates = (uint32_t)(kfmt != 0 && expected_rate <= 0.1L && (sk->s >= kDeviceOrderMinSketch || expected_rate > 3e-4L));
         }
         a.tile0 = tile;
         a.ntiles = cur.take;

@@ -3,6 +3,7 @@
 // Mirrors what `mash sketch` does with zlib + kseq.h before its hot loop (Mash 2.x
 // Sketch.cpp sketchFile); the files are the ones AuriClass passes through unchanged at
 // /root/reference/auriclass/classes.py:588 and :705.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -13,6 +14,7 @@
 
 #include <exception>
 #include <new>
+#include <thread>
 
 #include "mhx_internal.h"
 
@@ -66,9 +68,10 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     const size_t slack = GzInflater::kOvershoot + 16;
     out.assign(std::max<size_t>(hint, 1u << 16) + slack, 0);
     size_t n = 0;
+    const int threads = ingest_thread_budget();
     {   // bgzip output (assemblies kept indexable with faidx): the blocks side by side; what follows them, sequentially
         BgzfReader bgzf;
-        if (bgzf.start(raw.data(), got, 8)) {
+        if (bgzf.start(raw.data(), got, threads)) {
             for (;;) {
                 if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2);
                 const size_t r = bgzf.read(out.data() + n, out.size() - slack - n);
@@ -81,6 +84,26 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
             inf.set_input(raw.data() + off, got - off);
         }
     }
+    if (n == 0) { // one ordinary member of a few MB (a gzipped assembly): several threads, segments of 256 KiB
+        ParallelGunzip par;
+        if (par.start(raw.data(), got, threads, 1u << 20, 256u << 10)) {
+            bool ok = true;
+            for (;;) {
+                if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2);
+                const size_t r = par.read(out.data() + n, out.size() - slack - n);
+                if (r == (size_t)-1) { ok = false; break; }
+                if (r == 0) break;
+                n += r;
+            }
+            if (ok) {
+                const size_t off = par.consumed_input();
+                if (off >= got) { out.resize(n); return MHX_OK; }
+                inf.set_input(raw.data() + off, got - off);
+            } else {
+                n = 0; // declined or refused: the sequential decoder (and zlib behind it) has the last word
+            }
+        }
+    }
     for (;;) {
         const size_t r = inf.inflate(out.data() + n, out.size() - slack - n, out.data());
         if (r == (size_t)-1) return read_all_zlib(path, out); // zlib has the last word on a stream this decoder refuses
@@ -90,6 +113,24 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
     }
     out.resize(n);
     return MHX_OK;
+}
+
+int ingest_thread_budget()
+{
+    if (const char *e = getenv("MHX_INGEST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    long n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (long)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2 quota: "max 100000" or "<quota> <period>"
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<long>(n, (long)((quota + period - 1) / period));
+        fclose(f);
+    }
+    long ranks = 1;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1L, atol(e));
+    n /= ranks;
+    return (int)std::min(64L, std::max(2L, n));
 }
 
 static inline bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }

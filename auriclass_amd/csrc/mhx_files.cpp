@@ -535,9 +535,7 @@ static int bulk_load_plain(const char *path, BulkFile *f)
         f->d_buf = nullptr;
         return MHX_OK;
     }
-    int nthreads = (int)std::thread::hardware_concurrency();
-    if (nthreads > 16) nthreads = 16;
-    if (nthreads < 1) nthreads = 1;
+    int nthreads = std::min(16, ingest_thread_budget()); // pread threads: beyond 16 the page cache copy does not get faster
     uint64_t off = 0;
     int slot = 0;
     rc = MHX_OK;
@@ -646,10 +644,9 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         ChunkQueue q;
         std::vector<std::thread> threads;
         for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
-        // decoding threads per .gz file: the host's share (MHX_INGEST_THREADS, default 16 = the CPU share of a 1-GPU box)
-        // split over the files that are inflated side by side
-        int budget = 16;
-        if (const char *e = getenv("MHX_INGEST_THREADS")) budget = atoi(e);
+        // decoding threads per .gz file: the host's share (ingest_thread_budget: MHX_INGEST_THREADS, else the cores this
+        // process may run on divided by the ranks of the node) split over the files that are inflated side by side
+        const int budget = ingest_thread_budget();
         const int per_file = std::max(1, budget / (int)std::max<size_t>(1, queued.size()) - 1);
         for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, per_file, &q, &st[i]);
         IngestChunk c;

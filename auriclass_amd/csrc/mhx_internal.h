@@ -33,6 +33,10 @@ int msh_read_file(const char *path, SketchSet &s);
 
 // ---- FASTA/FASTQ ingest (mhx_fastx.cpp) -------------------------------------------------
 int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);
+// Host threads the ingest may use (inflate, pread): MHX_INGEST_THREADS, else the cores this process may run on
+// (sched_getaffinity, the cgroup's CPU quota if it has one) divided by the ranks of this node (LOCAL_WORLD_SIZE: one
+// process per GPU), at most 64, at least 2.
+int ingest_thread_budget();
 struct ParsedRecords {
     std::vector<uint8_t> seq;  // bases of counted records, '\n' after each record (MHX_FMT_SEQ)
     uint64_t records = 0;      // records with length >= k (mash's `count`)
@@ -87,7 +91,8 @@ class ParallelGunzip {
     ParallelGunzip &operator=(const ParallelGunzip &) = delete;
     // The compressed file (GzInflater::kInputPad readable bytes behind data[n - 1]).  false: not worth it or not possible
     // (small input, no second block start found, not gzip): use the sequential GzInflater.
-    bool start(const uint8_t *data, size_t n, int threads);
+    // min_bytes / seg_bytes (0: defaults of 8 MiB / 1 MiB): smaller inputs are declined / target size of a segment.
+    bool start(const uint8_t *data, size_t n, int threads, size_t min_bytes = 0, size_t seg_bytes = 0);
     // Output of the FIRST member, in order: bytes copied, 0 at its end (CRC-32 and length verified), (size_t)-1 on error.
     size_t read(uint8_t *dst, size_t want);
     // after the end: offset just behind the member's trailer (further members / padding follow there)

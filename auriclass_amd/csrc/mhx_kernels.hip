@@ -55,20 +55,20 @@ template <int K> __device__ __noinline__ uint32_t finish_candidate(const TileSme
     return process_deferred<K>(sm, code, T, ins);
 }
 
-// What the hash loop does with a candidate window: queue it behind the tile's work list (TileSmem), or -- queue full,
-// which takes more than ~1000 candidates in a tile: the first launches of a sketch, when T still admits every hash --
-// finish it on the spot.
-template <int K> struct CandidateQueue {
+// What the hash loop does with a candidate window in the queue form: it appends (group << 3) | window to the free tail
+// of the tile's work list (TileSmem) -- one LDS atomic and one 16-bit store, nothing else: no call, no threshold, no table
+// pointers in the hot loop's live set (round 2 finished an overflowing candidate on the spot through a non-inlined call,
+// which cost the kernel 32 bytes of scratch per lane for the registers saved around it).  A queue that overflows (more
+// than ~1000 candidates in a tile: only while T still admits a large share of all hashes, i.e. the first launches of a
+// sketch) is not used at all: the counter says so and the tile then finishes EVERY valid window through the generic
+// routine after the hash loop (sketch_tile_kernel), which tests each hash against T itself.
+struct CandidateQueue {
     TileSmem &sm;
     uint32_t first, cap; // list[first .. first + cap) is free
-    uint64_t T;
-    DeviceInserter ins;
     __device__ __forceinline__ void operator()(uint32_t group, int window) const
     {
-        const uint32_t code = (group << 3) | (uint32_t)window;
         const uint32_t slot = atomicAdd(&sm.misc[7], 1u);
-        if (slot < cap) sm.list[first + slot] = (uint16_t)code;
-        else if (finish_candidate<K>(sm, code, T, ins)) atomicAdd(&sm.misc[4], 1u);
+        if (slot < cap) sm.list[first + slot] = (uint16_t)((group << 3) | (uint32_t)window);
     }
 };
 
@@ -284,13 +284,25 @@ template <int K, int FMT, bool QUEUE> __global__ __launch_bounds__(kBlock, MHX_M
     const uint32_t limit = admission_limit(T);
     DeviceInserter ins{reinterpret_cast<unsigned long long *>(a.keys), a.cnts, a.slot_mask, stats};
     const uint32_t qcap = (uint32_t)kGroupsPerTile - nitems; // QUEUE: the work list's unused tail holds the candidate queue
-    CandidateQueue<K> queue{sm, nitems, qcap, T, ins};
+    CandidateQueue queue{sm, nitems, qcap};
     uint32_t ninsert = 0;
     for (uint32_t it = tid; it < nitems; it += kBlock) ninsert += process_group<K, QUEUE>(sm, sm.list[it], T, limit, ins, queue);
-    if (QUEUE) { // the candidates the loop has queued, one per lane
+    if (QUEUE) {
         __syncthreads();
-        const uint32_t ncand = sm.misc[7] < qcap ? sm.misc[7] : qcap;
-        for (uint32_t c = tid; c < ncand; c += kBlock) ninsert += finish_candidate<K>(sm, sm.list[nitems + c], T, ins);
+        const uint32_t ncand = sm.misc[7];
+        if (ncand <= qcap) { // the candidates the loop has queued, one per lane
+            for (uint32_t c = tid; c < ncand; c += kBlock) ninsert += finish_candidate<K>(sm, sm.list[nitems + c], T, ins);
+        } else { // the queue overflowed (T still admits a large share of all hashes): every valid window, whole hash, exact test
+            for (uint32_t it = tid; it < nitems; it += kBlock) {
+                const uint32_t g = sm.list[it];
+                uint32_t vmask = reinterpret_cast<const uint8_t *>(sm.valid)[g];
+                while (vmask) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(vmask);
+                    vmask &= vmask - 1u;
+                    ninsert += finish_candidate<K>(sm, (g << 3) | j, T, ins);
+                }
+            }
+        }
     }
     if (ninsert) atomicAdd(&sm.misc[4], ninsert);
     __syncthreads();
@@ -1153,6 +1165,10 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
 {
     __shared__ uint32_t seg_uni[kDistSegs][16], seg_com[kDistSegs][16];
     constexpr int RPS = kDistRanges / kDistSegs; // ranges per segment
+    // the range kernel gave up on this slice (a value range too crowded for its table or for byte counters): cpart holds
+    // cells it never wrote, the host discards this result and runs the generic kernel -- nothing to do here, and
+    // nothing to be walked on the strength of stale counts
+    if (w.params[1] != 0) return;
     const uint32_t pl = threadIdx.x & 15, seg = threadIdx.x >> 4;
     const uint32_t pair = blockIdx.x * 16 + pl;
     const bool live = pair < a.nq * a.nr;
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(256) void dist_finish_kernel(const DistArgs a, Dist
     if (sg == kDistSegs) denom = uni; // union smaller than s: everything counts
     else {
         uint32_t p = sg * RPS;
-        for (;; ++p) { // the cut range is inside this segment
+        for (; p + 1 < (sg + 1) * RPS; ++p) { // the cut range is inside this segment (its last range is the cut at the latest)
             const uint32_t c = cp[(uint64_t)p * cstride];
             const uint32_t u = (orr[p + 1] - orr[p]) + (oq[p + 1] - oq[p]) - c;
             if (uni + u >= S) break;

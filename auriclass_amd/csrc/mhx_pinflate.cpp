@@ -80,7 +80,8 @@ struct Segment {
     bool final_block_seen = false;
     uint32_t crc = 0;
     // hand-off
-    bool decoded = false, window_ready = false, done = false, failed = false;
+    bool decoded = false, window_ready = false, done = false;
+    std::atomic<bool> failed{false};      // set by the worker that owns the segment (error first), read by its neighbours
     uint8_t window[kWin];                 // last 32 KiB of this segment's output (resolved)
     uint32_t window_len = 0;              // < kWin only for the first segment of a short stream
     std::string error;
@@ -113,7 +114,12 @@ struct ParallelGunzip::Impl {
     std::atomic<size_t> next_task{0};
     size_t consumed = 0;     // segments the consumer is done with (guards the look-ahead)
     size_t lookahead = 8;
-    bool abort = false;
+    std::atomic<bool> abort{false};
+    // memory bound: bytes of decoded segments the consumer has not taken yet (16-bit symbols + bytes = 3 per output
+    // byte); a worker does not START a further segment while this exceeds the budget -- except the one the consumer
+    // waits for, so the pipeline cannot stall
+    size_t outstanding = 0;
+    size_t budget = (size_t)768 << 20;
     // consumer state
     size_t cur = 0, cur_off = 0;
     uint32_t crc_all = 0;
@@ -261,8 +267,16 @@ void ParallelGunzip::Impl::decode_segment(size_t j)
         for (uint32_t w = 0; w < kWin; ++w) s.sym()[w] = (uint16_t)(kMarker | w);
     }
     size_t so = kWin, bo = 0; // positions (elements) in sym resp. out: the buffers may move when they grow
-    auto fail = [&](const char *msg) { s.failed = true; s.error = msg; };
+    auto fail = [&](const char *msg) { s.error = msg; s.failed = true; };
+    // A segment's buffers grow with what it inflates to, and on repetitive data the symbolic form never ends (a marker
+    // copied at distance 1 stays a marker): 2 GB of 'N' reads in a 12 MB file would put gigabytes into the look-ahead.
+    // Beyond this many bytes the multi-threaded decoder declines the file and the sequential one, which streams in
+    // constant memory like zlib, takes over (FASTQ text inflates 3-6x).
+    static const size_t max_ratio = getenv("MHX_PINFLATE_MAX_RATIO") ? (size_t)atol(getenv("MHX_PINFLATE_MAX_RATIO")) : 16;
+    const size_t seg_limit = std::max<size_t>(comp_bytes * max_ratio, (size_t)8 << 20);
+    static const char *const too_much = "compression ratio beyond the multi-threaded decoder's memory bound";
     for (;;) {
+        if (abort.load(std::memory_order_relaxed)) return fail("aborted");
         const uint64_t pos = r.bitpos(z);
         if (pos == s.stop_bit) break;
         if (s.stop_bit != ~0ull && pos > s.stop_bit) return fail("segment ran past the start of its successor");
@@ -274,6 +288,7 @@ void ParallelGunzip::Impl::decode_segment(size_t j)
         if (type == 0) {
             r.unread();
             if (r.in > r.in_end || (size_t)(r.in_end - r.in) < stored) return fail("unexpected end of stored block");
+            if ((symbolic ? so - kWin : bo) + stored > seg_limit) return fail(too_much);
             if (symbolic) {
                 s.sym_buf.ensure(2 * (so + stored + 1024));
                 uint16_t *d = s.sym() + so;
@@ -292,6 +307,7 @@ void ParallelGunzip::Impl::decode_segment(size_t j)
                 so = (size_t)(o - s.sym());
                 if (st == kBlockError) return fail(err);
                 if (st == kBlockEnd) break;
+                if (so - kWin > seg_limit) return fail(too_much);
                 s.sym_buf.ensure(s.sym_buf.cap * 2);
             }
         } else {
@@ -301,6 +317,7 @@ void ParallelGunzip::Impl::decode_segment(size_t j)
                 bo = (size_t)(o - s.out());
                 if (st == kBlockError) return fail(err);
                 if (st == kBlockEnd) break;
+                if (bo > seg_limit) return fail(too_much);
                 s.out_buf.ensure(s.out_buf.cap * 2);
             }
         }
@@ -339,20 +356,21 @@ void ParallelGunzip::Impl::worker()
         if (j >= segs.size()) return;
         {   // bounded look-ahead: decoded segments wait in memory until the consumer has taken them
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return abort || j < consumed + lookahead; });
+            cv.wait(lk, [&] { return abort || (j < consumed + lookahead && (j == consumed || outstanding < budget)); });
             if (abort) return;
         }
         Segment &s = *segs[j];
         const auto t_start = std::chrono::steady_clock::now();
         try {
             decode_segment(j);
-        } catch (const std::bad_alloc &) {
+        } catch (const std::exception &e) { // bad_alloc, system_error: the segment fails, the process does not
+            s.error = e.what();
             s.failed = true;
-            s.error = "out of memory";
         }
         {
             std::lock_guard<std::mutex> lk(m);
             s.decoded = true;
+            outstanding += 3 * s.n_out;
         }
         cv.notify_all();
         const auto t_decoded = std::chrono::steady_clock::now();
@@ -366,8 +384,8 @@ void ParallelGunzip::Impl::worker()
                 if (abort) return;
             }
             t_waited = std::chrono::steady_clock::now();
-            if (p.failed) { s.failed = true; s.error = p.error; }
-            else {
+            if (p.failed) { s.error = p.error; s.failed = true; }
+            else try {
                 // One table look-up per symbol, no branch: symbols 0..255 map to themselves, marker 0x8000 | w to byte w of
                 // the 32 KiB in front of this segment (index kWin - 1 = the byte right before it).  A marker that reaches in
                 // front of the stream's first byte (only possible with a corrupt stream) is caught by a sentinel scan below.
@@ -412,8 +430,11 @@ void ParallelGunzip::Impl::worker()
                 }
                 cv.notify_all();
                 resolve(0, std::min(tail_from, s.n_sym));
-                if (bad) { s.failed = true; s.error = "invalid distance too far back"; }
+                if (bad) { s.error = "invalid distance too far back"; s.failed = true; }
                 give(pool_sym, std::move(s.sym_buf));
+            } catch (const std::exception &e) { // the 64 KiB table
+                s.error = e.what();
+                s.failed = true;
             }
         } else if (!s.failed) {
             std::lock_guard<std::mutex> lk(m);
@@ -444,7 +465,7 @@ ParallelGunzip::~ParallelGunzip() { delete impl_; }
 const std::string &ParallelGunzip::error() const { return impl_->error; }
 size_t ParallelGunzip::consumed_input() const { return impl_->trailer_off ? impl_->trailer_off + 8 : 0; }
 
-bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads)
+bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads, size_t min_bytes_arg, size_t seg_bytes_arg)
 {
     Impl &p = *impl_;
     p.z = z;
@@ -452,12 +473,14 @@ bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads)
     p.nthreads = threads;
     p.deflate_off = member_header_len(z, n);
     // small inputs: the sequential decoder is as fast (MHX_PINFLATE_MIN / MHX_PINFLATE_SEGMENT: test knobs)
-    static const size_t min_bytes = getenv("MHX_PINFLATE_MIN") ? (size_t)atol(getenv("MHX_PINFLATE_MIN")) : (8u << 20);
+    static const size_t min_env = getenv("MHX_PINFLATE_MIN") ? (size_t)atol(getenv("MHX_PINFLATE_MIN")) : 0;
+    const size_t min_bytes = min_env ? min_env : (min_bytes_arg ? min_bytes_arg : (8u << 20));
     if (!p.deflate_off || threads < 2 || n < min_bytes) return false;
     // segment targets: equal shares of the compressed bytes, ~1 MiB each (small segments keep the working set of a worker
     // -- 16-bit symbols plus bytes of ~10 MB of output -- near the caches and let the buffer pool recycle early), at least
     // two per thread
-    static const size_t seg_bytes = getenv("MHX_PINFLATE_SEGMENT") ? (size_t)atol(getenv("MHX_PINFLATE_SEGMENT")) : (1u << 20);
+    static const size_t seg_env = getenv("MHX_PINFLATE_SEGMENT") ? (size_t)atol(getenv("MHX_PINFLATE_SEGMENT")) : 0;
+    const size_t seg_bytes = seg_env ? seg_env : (seg_bytes_arg ? seg_bytes_arg : (1u << 20));
     size_t nseg = std::max<size_t>((size_t)threads * 2, n / seg_bytes);
     if (nseg > 65536) nseg = 65536;
     const uint64_t first_bit = (uint64_t)p.deflate_off * 8, end_bit = (uint64_t)n * 8;
@@ -467,16 +490,23 @@ bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads)
     {   // block search for every target, all threads
         std::atomic<size_t> next{1};
         std::vector<std::thread> ts;
-        for (int t = 0; t < threads; ++t)
-            ts.emplace_back([&] {
-                for (;;) {
-                    const size_t j = next.fetch_add(1);
-                    if (j >= nseg) return;
-                    const uint64_t from = first_bit + share * j, to = std::min(end_bit - 64, from + share);
-                    uint64_t found;
+        auto search = [&] {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= nseg) return;
+                const uint64_t from = first_bit + share * j, to = std::min(end_bit - 64, from + share);
+                uint64_t found;
+                try {
                     if (from < to && p.find_block_start(from, to, &found)) starts[j] = found;
+                } catch (const std::exception &) { // out of memory in a trial decode: no start found in this share
                 }
-            });
+            }
+        };
+        try {
+            for (int t = 0; t < threads; ++t) ts.emplace_back(search);
+        } catch (const std::system_error &) { // the host would not give us another thread: the ones we have do the work
+        }
+        if (ts.empty()) search();
         for (auto &t : ts) t.join();
     }
     for (size_t j = 0; j < nseg; ++j) {
@@ -489,7 +519,12 @@ bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads)
     }
     if (p.segs.size() < 2) { p.segs.clear(); return false; }
     p.lookahead = (size_t)threads * 2;
-    for (int t = 0; t < threads; ++t) p.workers.emplace_back([&p] { p.worker(); });
+    if (const char *e = getenv("MHX_PINFLATE_BUDGET_MB")) p.budget = (size_t)atol(e) << 20;
+    try {
+        for (int t = 0; t < threads; ++t) p.workers.emplace_back([&p] { p.worker(); });
+    } catch (const std::system_error &) {
+        if (p.workers.empty()) { p.segs.clear(); return false; } // no thread at all: the sequential decoder
+    }
     return true;
 }
 
@@ -534,6 +569,7 @@ size_t ParallelGunzip::read(uint8_t *dst, size_t want)
             {
                 std::lock_guard<std::mutex> lk(p.m);
                 p.consumed = p.cur + 1;
+                p.outstanding -= std::min(p.outstanding, 3 * s.n_out);
             }
             p.cv.notify_all();
             ++p.cur;
@@ -600,7 +636,7 @@ struct BgzfReader::Impl {
             }
             const Block &b = blocks[i];
             bool ok = true;
-            if (b.isize) {
+            { // (also a block that announces no data, e.g. the end-of-file marker: its CRC and length are checked like any other's)
                 inf.set_input(z + b.off, b.csize); // one member: header, deflate stream, CRC-32 and length (both checked)
                 size_t got = 0;
                 // room for one byte more than the block announces: the decoder then runs through the end-of-block symbol
@@ -722,17 +758,21 @@ extern "C" int mhx_gunzip_buffer_mt(const void *gz, size_t n, void *out, size_t 
             off = bgzf.consumed_input();
         }
         ParallelGunzip par;
+        bool declined = false;
         if (off == 0 && threads >= 2 && par.start(in.data(), n, threads)) {
             std::vector<uint8_t> piece(4u << 20);
             for (;;) {
                 const size_t room = dst && total < cap ? cap - total : 0;
                 const size_t got = room >= piece.size() ? par.read(dst + total, room) : par.read(piece.data(), piece.size());
-                if (got == (size_t)-1) return fail(MHX_E_FORMAT, "gunzip: %s", par.error().c_str());
+                if (got == (size_t)-1) {
+                    if (par.error().find("memory bound") != std::string::npos) { total = 0; declined = true; break; } // the sequential decoder streams it
+                    return fail(MHX_E_FORMAT, "gunzip: %s", par.error().c_str());
+                }
                 if (got == 0) break;
                 if (room < piece.size() && dst && total < cap) memcpy(dst + total, piece.data(), std::min(got, cap - total));
                 total += got;
             }
-            off = par.consumed_input();
+            off = declined ? 0 : par.consumed_input();
         }
         // further members (or everything, when the parallel decoder declined): the sequential decoder
         if (off < n) {

@@ -569,10 +569,20 @@ MHX_HD void canonical_words(const uint32_t (&U)[ND + 1], const uint32_t (&R)[ND 
             uint32_t Uc[ND + 1], Rc[ND + 1];
 #pragma unroll
             for (int i = 0; i < ND + 1; ++i) { Uc[i] = opaque(U[i]); Rc[i] = opaque(R[i]); }
-            uint32_t wf[8], wr[8];
-            extract_words<K, OF>(Uc, wf);
-            extract_words<K, OR>(Rc, wr);
-            rc = rc_is_smaller_full<NW>(wf, wr);
+            // word by word, most significant first: two temporaries instead of two extracted windows (the hash loop has no
+            // registers to spare, and a spill here gives the whole kernel a scratch allocation)
+            constexpr uint32_t last_mask = (K % 4) ? (1u << (8 * (K % 4))) - 1u : 0xFFFFFFFFu;
+            bool rc_less = false, decided = false;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                uint32_t f = funnel(Uc[OF / 4 + i + 1], Uc[OF / 4 + i], OF % 4);
+                uint32_t r = funnel(Rc[OR / 4 + i + 1], Rc[OR / 4 + i], OR % 4);
+                if (i == NW - 1) { f &= last_mask; r &= last_mask; }
+                const uint32_t fb = opaque(__builtin_bswap32(f)), rb = opaque(__builtin_bswap32(r));
+                rc_less = decided ? rc_less : (rb < fb);
+                decided = decided || (fb != rb);
+            }
+            rc = rc_less;
         }
         // select the source dwords first, extract once
         uint32_t S[NW + 1];

@@ -237,6 +237,7 @@ class Sketcher:
         h = ctypes.c_void_p()
         _check(load().mhx_sketcher_create_scaled(k, s, self.m, expected_bytes, budget_scale, ctypes.byref(h)))
         self._h = h
+        self._keep: list = []   # owners of pushed device memory, released at the next settling call
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -251,9 +252,18 @@ class Sketcher:
 
     def reset(self) -> None:
         _check(load().mhx_sketcher_reset(self._h))
+        self._keep.clear()
 
-    def push_device(self, ptr: int, nbytes: int, fmt: int) -> None:
+    def push_device(self, ptr: int, nbytes: int, fmt: int, keep=None) -> None:
+        """Feeds `nbytes` of device memory at `ptr` (asynchronous, on the engine's stream).
+        LIFETIME: the bytes must stay valid AND unchanged until sync(), finish(), an export or reset() has returned --
+        a synchronisation of the stream alone is not enough: FASTQ spans whose reads are longer than ~2.7 kb are read
+        a second time by a repair pass that those calls start (include/mhx.h).  `keep`: any object (e.g. the torch
+        tensor that owns the memory) to be referenced by this sketcher until then, so that dropping the caller's last
+        reference cannot hand the memory to someone else in between."""
         _check(load().mhx_sketcher_push_device(self._h, ctypes.c_void_p(ptr), nbytes, fmt))
+        if keep is not None:
+            self._keep.append(keep)
 
     def push_host(self, data, fmt: int) -> None:
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
@@ -262,12 +272,14 @@ class Sketcher:
 
     def sync(self) -> None:
         _check(load().mhx_sketcher_sync(self._h))
+        self._keep.clear()
 
     def finish(self) -> Tuple[np.ndarray, np.ndarray]:
         hashes = np.zeros(self.s, dtype=np.uint64)
         counts = np.zeros(self.s, dtype=np.uint32)
         n = ctypes.c_uint32(0)
         _check(load().mhx_sketcher_finish(self._h, hashes.ctypes.data, counts.ctypes.data, ctypes.byref(n)))
+        self._keep.clear()
         return hashes[:n.value].copy(), counts[:n.value].copy()
 
     def stats(self) -> dict:

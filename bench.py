@@ -120,7 +120,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-sketch", default="", help="rank 0 saves the final sketch (hashes, counts) to this .npz")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the sharded == unsharded check (rank 0 re-sketches all shards)")
-    args = ap.parse_args()
+    # ranks started by this script's own launcher get their arguments through the environment: torch.distributed.run's
+    # parser claims abbreviations of its own options even behind the script name (`--s` -> "ambiguous option")
+    forwarded = os.environ.get("MHX_BENCH_ARGV") if "WORLD_SIZE" in os.environ else None
+    args = ap.parse_args(json.loads(forwarded)) if forwarded else ap.parse_args()
 
     nproc = os.cpu_count() or 1
     try:
@@ -143,9 +146,9 @@ def main() -> None:
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MHX_BENCH_ARGV=json.dumps(sys.argv[1:]))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

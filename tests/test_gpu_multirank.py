@@ -24,9 +24,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _input(n_reads):
+def _input(n_reads, sub_rate=0.005):
     genome = synth.make_genome(200_000, seed=21)
-    return synth.make_fastq(genome, n_reads, READ_LEN, seed=22, device="cpu").numpy()
+    return synth.make_fastq(genome, n_reads, READ_LEN, seed=22, sub_rate=sub_rate, device="cpu").numpy()
 
 
 def _seqs(fq_bytes):
@@ -42,7 +42,7 @@ def _exchange(sk, form, k, s, m):
     return multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
 
 
-def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device"):
+def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rate=0.005):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -50,7 +50,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device"):
     from auriclass_amd import engine
 
     engine.init(0)
-    fq = _input(n_reads)
+    fq = _input(n_reads, sub_rate)
     rb = synth.record_bytes(READ_LEN)
     lo, hi = multigpu.shard_bounds(n_reads, world, rank)
     shard = torch.from_numpy(fq[lo * rb:hi * rb]).to("cuda:0")
@@ -102,9 +102,10 @@ def test_exchange_whose_shards_exceed_a_fixed_slab(tmp_path):
     fixed slab ALWAYS overflowed).  The slabs are sized from the exchanged headers instead."""
     from oracle import mash_oracle as mo
 
-    world, k, s, m, n_reads = 2, 21, 200, 3, 60_000
-    mp.spawn(_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path), "device"), nprocs=world, join=True)
-    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_input(n_reads).tobytes()), k, s, m)
+    world, k, s, m, n_reads, sub_rate = 2, 21, 1000, 3, 60_000, 0.03   # 3 % substitutions: ~30 error k-mers per solid one
+    mp.spawn(_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path), "device", sub_rate), nprocs=world, join=True)
+    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_input(n_reads, sub_rate).tobytes()), k, s, m)
+    assert len(bf_h) == s
     for r in range(world):
         assert max(np.load(tmp_path / f"n{r}.npy")) > 4 * s + 4096
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), bf_h)
@@ -136,7 +137,7 @@ def _nccl_worker(rank, world, port, k, s, m, n_reads, out_dir):
     sk2.push_device(fq.data_ptr(), 5 * rb, engine.FMT_FASTQ4)
     want_h, _ = sk2.finish()
     tiny_h, _ = multigpu.exchange_and_merge_device(sk2, torch.device("cuda", 0))
-    assert np.array_equal(tiny_h, want_h) and 0 < len(tiny_h) < s
+    assert np.array_equal(tiny_h, want_h) and len(tiny_h) < s and (m > 1 or len(tiny_h) > 0)
     sk.close()
     sk2.close()
     dist.destroy_process_group()

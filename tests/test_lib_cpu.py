@@ -270,6 +270,27 @@ def test_parallel_gunzip_equals_zlib(lib, monkeypatch):
     assert engine.gunzip(blob + b"\0" * 333, 4) == b"".join(parts)
 
 
+def test_parallel_gunzip_declines_a_stream_that_would_not_fit_in_memory(lib, monkeypatch, capfd):
+    """A highly repetitive member (all-N reads: 160:1) never leaves the symbolic form, and every segment of the look-ahead
+    would hold 3 bytes per inflated byte: the multi-threaded decoder gives such a member up at 16x its compressed size per
+    segment (>= 8 MiB) and the sequential decoder, which streams in constant memory like zlib, produces the bytes."""
+    monkeypatch.setenv("MHX_PINFLATE_MIN", "1")
+    monkeypatch.setenv("MHX_PINFLATE_SEGMENT", "131072")
+    monkeypatch.setenv("MHX_PINFLATE_DEBUG", "1")
+    rec = b"@r\n" + b"N" * 150 + b"\n+\n" + b"#" * 150 + b"\n"
+    data = rec * (120_000_000 // len(rec))
+    z = _gz(data, 6)
+    assert len(z) * 100 < len(data)
+    capfd.readouterr()
+    assert engine.gunzip(z, 4, size_hint=len(data)) == data
+    assert "FAILED" in capfd.readouterr().err          # the parallel decoder did engage, and gave up
+    # ordinary FASTQ text stays far below the bound
+    rng = np.random.default_rng(5)
+    text = _fastq_like(rng, 20_000)
+    assert engine.gunzip(_gz(text, 6), 4) == text
+    assert "FAILED" not in capfd.readouterr().err
+
+
 def test_parallel_gunzip_refuses_what_zlib_refuses(lib, monkeypatch):
     """Truncations and bit flips anywhere in the stream: an error, never different bytes (every segment hand-off is checked
     against the successor's block boundary, the member's CRC-32 and length at the end)."""
