@@ -76,6 +76,9 @@ extern "C" void mhx_shutdown(void)
 {
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
+    if (g.fasta.sk) mhx_sketcher_destroy(g.fasta.sk);
+    hipFree(g.fasta.d_raw); hipFree(g.fasta.d_out); hipFree(g.fasta.d_ws); hipFree(g.fasta.d_seps);
+    if (g.fasta.h_words) hipHostFree(g.fasta.h_words);
     hipFree(g.dist_ws);
     if (g.copy_stream) hipStreamSynchronize(g.copy_stream);
     for (int i = 0; i < Engine::kPinnedSlots; ++i) {

@@ -14,6 +14,21 @@ namespace mhx {
         if (e_ != hipSuccess) return fail(MHX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// FASTA through the device parser (mhx_files.cpp), kept between files and calls: device buffers sized to the largest file
+// seen, one sketcher per (k, s) that is reset between files (no hipMalloc / hipFree and no 200 MB table set-up per file)
+constexpr uint32_t kFastaSepsInline = 4096; // record positions that come back with the first synchronisation
+struct FastaCtx {
+    uint8_t *d_raw = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    uint64_t *d_seps = nullptr;
+    size_t raw_cap = 0, ws_cap = 0;
+    uint32_t seps_cap = 0;
+    uint64_t *h_words = nullptr; // pinned: [0] stream size, [1] {format flag, #separators}, [2 ..) the first kFastaSepsInline separators
+    mhx_sketcher *sk = nullptr;
+    int k = 0;
+    uint32_t s = 0;
+    uint64_t scale = 0;
+};
+
 // ---- engine state ---------------------------------------------------------------------
 struct Engine {
     bool ready = false;
@@ -29,6 +44,7 @@ struct Engine {
     uint8_t *pinned[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pinned_free[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
+    FastaCtx fasta;
 };
 extern Engine g;
 int require_engine();

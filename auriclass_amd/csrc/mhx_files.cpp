@@ -748,41 +748,66 @@ bool nth_header(const uint8_t *b, size_t n, uint64_t idx, std::string &name, std
 }
 } // namespace
 
-static int sketch_fasta_on_device(const std::vector<uint8_t> &raw, int k, uint32_t s, std::vector<uint64_t> &hashes, FastaInfo &info)
+// One FASTA file, bytes in host memory (a pinned staging slot or a vector) -> its reference sketch.  Device buffers and the
+// sketcher live in g.fasta between files and calls; two stream synchronisations per file (record layout, sketch).
+static int sketch_fasta_on_device(const uint8_t *raw, uint64_t n, int k, uint32_t s, std::vector<uint64_t> &hashes, FastaInfo &info)
 {
-    const uint64_t n = raw.size();
     if (n == 0 || raw[0] != '>' || n > 0x7FFFFFFF00ull) return kFastaNotForDevice;
+    FastaCtx &c = g.fasta;
     size_t os, oi, oo, of;
     const size_t ws_bytes = fasta_workspace_bytes(n, &os, &oi, &oo, &of);
     const uint64_t ntiles = (n + kFastaTile - 1) / kFastaTile;
-    DeviceBuf d_raw, d_out, d_ws, d_seps;
-    uint32_t seps_cap = (uint32_t)std::min<uint64_t>(n / 2 + 16, 1u << 20);
-    if (d_raw.alloc(n + 64) != hipSuccess || d_out.alloc(n + 64) != hipSuccess || d_ws.alloc(ws_bytes) != hipSuccess ||
-        d_seps.alloc((size_t)seps_cap * 8) != hipSuccess)
-        return fail(MHX_E_HIP, "hipMalloc failed for the FASTA buffers (%llu bytes)", (unsigned long long)n);
-    HIPCHK(hipMemcpyAsync(d_raw.p, raw.data(), n, hipMemcpyHostToDevice, g.stream));
-    uint64_t total = 0;
-    uint32_t fl[2] = {0, 0};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(launch_fasta_compact((const uint8_t *)d_raw.p, n, (uint8_t *)d_ws.p, (uint8_t *)d_out.p, (uint64_t *)d_seps.p, seps_cap, g.stream));
-        HIPCHK(hipMemcpyAsync(&total, (uint8_t *)d_ws.p + oo + 8 * ntiles, 8, hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipMemcpyAsync(fl, (uint8_t *)d_ws.p + of, 8, hipMemcpyDeviceToHost, g.stream));
+    if (!c.h_words) HIPCHK(hipHostMalloc((void **)&c.h_words, (2 + (size_t)kFastaSepsInline) * sizeof(uint64_t), hipHostMallocDefault));
+    if (c.raw_cap < n + 64 || c.ws_cap < ws_bytes) { // grow with room: the next assembly is about as large as this one
         HIPCHK(hipStreamSynchronize(g.stream));
+        hipFree(c.d_raw); hipFree(c.d_out); hipFree(c.d_ws);
+        c.d_raw = c.d_out = c.d_ws = nullptr;
+        c.raw_cap = c.ws_cap = 0;
+        const size_t want = (size_t)(n + n / 4 + (1u << 20));
+        size_t os2, oi2, oo2, of2;
+        const size_t ws_want = fasta_workspace_bytes(want, &os2, &oi2, &oo2, &of2);
+        if (hipMalloc((void **)&c.d_raw, want + 64) != hipSuccess || hipMalloc((void **)&c.d_out, want + 64) != hipSuccess ||
+            hipMalloc((void **)&c.d_ws, ws_want) != hipSuccess)
+            return fail(MHX_E_HIP, "hipMalloc failed for the FASTA buffers (%llu bytes)", (unsigned long long)n);
+        c.raw_cap = want + 64;
+        c.ws_cap = ws_want;
+    }
+    if (!c.d_seps) {
+        c.seps_cap = 1u << 16;
+        if (hipMalloc((void **)&c.d_seps, (size_t)c.seps_cap * 8) != hipSuccess) { c.seps_cap = 0; return fail(MHX_E_HIP, "hipMalloc failed for the FASTA record positions"); }
+    }
+    HIPCHK(hipMemcpyAsync(c.d_raw, raw, n, hipMemcpyHostToDevice, g.stream));
+    uint64_t total = 0;
+    uint32_t nsep = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(launch_fasta_compact(c.d_raw, n, c.d_ws, c.d_out, c.d_seps, c.seps_cap, g.stream));
+        HIPCHK(hipMemcpyAsync(&c.h_words[0], c.d_ws + oo + 8 * ntiles, 8, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipMemcpyAsync(&c.h_words[1], c.d_ws + of, 8, hipMemcpyDeviceToHost, g.stream));
+        // the record positions of an assembly (tens to hundreds of contigs) ride along with the same synchronisation
+        HIPCHK(hipMemcpyAsync(&c.h_words[2], c.d_seps, (size_t)std::min(c.seps_cap, kFastaSepsInline) * 8, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        total = c.h_words[0];
+        uint32_t fl[2];
+        memcpy(fl, &c.h_words[1], 8);
         if (fl[0] & 1u) return kFastaNotForDevice;
-        if (fl[1] <= seps_cap) break;
+        nsep = fl[1];
+        if (nsep <= c.seps_cap) break;
         if (attempt) return fail(MHX_E_INTERNAL, "FASTA record list kept growing");
-        seps_cap = fl[1] + 16; // more records than the first guess: once more with room for all of them
-        hipFree(d_seps.p);
-        d_seps.p = nullptr;
-        if (d_seps.alloc((size_t)seps_cap * 8) != hipSuccess) return fail(MHX_E_HIP, "hipMalloc failed for %u FASTA record positions", seps_cap);
+        hipFree(c.d_seps); // more records than there was room for: once more with room for all of them
+        c.d_seps = nullptr;
+        c.seps_cap = 0;
+        const uint32_t want = nsep + nsep / 4 + 16;
+        if (hipMalloc((void **)&c.d_seps, (size_t)want * 8) != hipSuccess) return fail(MHX_E_HIP, "hipMalloc failed for %u FASTA record positions", want);
+        c.seps_cap = want;
     }
     // records: separator i sits in front of record i; its length is the distance to the next separator (or the end)
-    std::vector<uint64_t> seps(fl[1]);
-    if (!seps.empty()) {
-        HIPCHK(hipMemcpyAsync(seps.data(), d_seps.p, seps.size() * 8, hipMemcpyDeviceToHost, g.stream));
+    std::vector<uint64_t> seps(nsep);
+    if (nsep && nsep <= kFastaSepsInline) memcpy(seps.data(), &c.h_words[2], (size_t)nsep * 8);
+    else if (nsep) {
+        HIPCHK(hipMemcpyAsync(seps.data(), c.d_seps, seps.size() * 8, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
-        std::sort(seps.begin(), seps.end());
     }
+    std::sort(seps.begin(), seps.end());
     info = FastaInfo();
     uint64_t first_counted = ~0ull;
     for (size_t i = 0; i < seps.size(); ++i) {
@@ -795,26 +820,65 @@ static int sketch_fasta_on_device(const std::vector<uint8_t> &raw, int k, uint32
     }
     // a last header line without its newline has no separator and no sequence: it does not count either way
     if (info.records == 0) return MHX_OK; // the caller reports "Did not find fasta records"
-    nth_header(raw.data(), raw.size(), first_counted, info.first_name, info.first_comment);
+    nth_header(raw, n, first_counted, info.first_name, info.first_comment);
     uint64_t boost = 1;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        mhx_sketcher *sk = nullptr;
-        int rc = create_sketcher(k, s, 1, total, boost, &sk);
-        if (rc) return rc;
-        rc = mhx_sketcher_push_device(sk, d_out.p, total, MHX_FMT_SEQ);
+        int rc = MHX_OK;
+        if (!c.sk || c.k != k || c.s != s || c.scale != boost) { // one sketcher per (k, s), reset between files
+            if (c.sk) mhx_sketcher_destroy(c.sk);
+            c.sk = nullptr;
+            rc = create_sketcher(k, s, 1, 0, boost, &c.sk);
+            if (rc) return rc;
+            c.k = k; c.s = s; c.scale = boost;
+        } else {
+            rc = mhx_sketcher_reset(c.sk);
+            if (rc) return rc;
+        }
+        rc = mhx_sketcher_push_device(c.sk, c.d_out, total, MHX_FMT_SEQ);
         uint32_t nh = 0;
-        std::vector<uint32_t> counts(s);
         if (!rc) {
             hashes.resize(s);
-            rc = mhx_sketcher_finish(sk, hashes.data(), counts.data(), &nh);
+            rc = mhx_sketcher_finish(c.sk, hashes.data(), nullptr, &nh);
         }
-        mhx_sketcher_destroy(sk);
         if (rc == MHX_E_CAPACITY) { boost *= 16; continue; }
         if (rc) return rc;
         hashes.resize(nh);
         return MHX_OK;
     }
     return fail(MHX_E_CAPACITY, "could not size the device table for this input");
+}
+
+// One input of `mash sketch` without -r, in host memory: an uncompressed file of up to 64 MiB is pread() straight into
+// a pinned staging slot (no zero-fill, no pageable bounce on the way to the GPU), anything else is read / inflated into
+// a vector.  Runs on a helper thread for file i + 1 while file i is on the GPU.
+struct FastaInput {
+    std::vector<uint8_t> owned;
+    const uint8_t *data = nullptr;
+    uint64_t n = 0;
+    int slot = -1;
+    int rc = MHX_OK;
+    std::string error; // (mhx_last_error is thread-local: the message travels with the input)
+};
+
+static void load_fasta_input(const char *path, int slot, bool pinned_ok, FastaInput *in)
+{
+    (void)hipSetDevice(g.device);
+    struct stat sb;
+    if (pinned_ok && !is_gzip_file(path) && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && (size_t)sb.st_size + 64 <= kBulkBlock) {
+        const int fd = open(path, O_RDONLY);
+        if (fd >= 0) {
+            bool ok = hipEventSynchronize(g.pinned_free[slot]) == hipSuccess;
+            const size_t len = (size_t)sb.st_size;
+            const int nthreads = len >= (4u << 20) ? std::min(8, ingest_thread_budget()) : 1;
+            ok = ok && parallel_pread(fd, g.pinned[slot], 0, len, nthreads);
+            close(fd);
+            if (ok) { in->data = g.pinned[slot]; in->n = len; in->slot = slot; return; }
+        }
+    }
+    in->rc = read_all_maybe_gz(path, in->owned);
+    if (in->rc) in->error = mhx_last_error();
+    in->data = in->owned.data();
+    in->n = in->owned.size();
 }
 
 static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, uint32_t s, int reads, uint32_t min_mult,
@@ -910,14 +974,23 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
         err += "Estimated coverage:    " + fmt_g(mult) + "\n";
         if (est_genome_size) *est_genome_size = set_size;
     } else {
+        // one reference per file; file i + 1 is read (and inflated) on a helper thread while file i is on the GPU
+        const bool pinned_ok = !getenv("MHX_HOST_FASTA") && ensure_pinned_ring() == MHX_OK;
+        if (!pinned_ok) { clear_error(); (void)hipGetLastError(); }
+        std::vector<FastaInput> inputs(n_paths);
+        std::thread loader;
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{loader};
+        load_fasta_input(paths[0], 0, pinned_ok, &inputs[0]);
         for (int i = 0; i < n_paths; ++i) {
+            if (loader.joinable()) loader.join();
+            if (i + 1 < n_paths) loader = std::thread(load_fasta_input, paths[i + 1], (i + 1) % Engine::kPinnedSlots, pinned_ok, &inputs[i + 1]);
+            FastaInput &in = inputs[i];
             err += std::string("Sketching ") + paths[i] + "...\n";
-            rc = read_all_maybe_gz(paths[i], loaded[i].raw);
-            if (rc) return rc;
+            if (in.rc) return fail(in.rc, "%s", in.error.c_str());
             if (!getenv("MHX_HOST_FASTA")) { // plain FASTA: parsed on the device
                 RefSketch ref;
                 FastaInfo info;
-                rc = sketch_fasta_on_device(loaded[i].raw, k, s, ref.hashes, info);
+                rc = sketch_fasta_on_device(in.data, in.n, k, s, ref.hashes, info);
                 if (rc < 0) return rc;
                 if (rc == MHX_OK) {
                     if (info.records == 0) return no_records(paths[i]);
@@ -925,16 +998,19 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
                     ref.comment = make_comment(info.first_name, info.first_comment, info.records);
                     ref.length = info.total_length;
                     set.refs.push_back(std::move(ref));
-                    loaded[i] = Loaded();
+                    in = FastaInput();
                     continue;
                 }
             }
+            if (in.slot >= 0) in.owned.assign(in.data, in.data + in.n); // the record parser path keeps the bytes beyond this slot's turn
+            loaded[i].raw.swap(in.owned);
+            in = FastaInput();
             rc = parse_fastx(loaded[i].raw.data(), loaded[i].raw.size(), k, loaded[i].rec);
             if (rc) return rc;
             if (loaded[i].rec.records == 0) return no_records(paths[i]);
             RefSketch ref;
-            std::vector<Loaded *> in{&loaded[i]};
-            rc = sketch_reference(in, k, s, 1, false, ref.hashes, ref.counts, nullptr);
+            std::vector<Loaded *> in2{&loaded[i]};
+            rc = sketch_reference(in2, k, s, 1, false, ref.hashes, ref.counts, nullptr);
             if (rc) return rc;
             ref.counts.clear();
             ref.name = paths[i];

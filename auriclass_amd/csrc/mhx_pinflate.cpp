@@ -272,7 +272,7 @@ void ParallelGunzip::Impl::decode_segment(size_t j)
     // copied at distance 1 stays a marker): 2 GB of 'N' reads in a 12 MB file would put gigabytes into the look-ahead.
     // Beyond this many bytes the multi-threaded decoder declines the file and the sequential one, which streams in
     // constant memory like zlib, takes over (FASTQ text inflates 3-6x).
-    static const size_t max_ratio = getenv("MHX_PINFLATE_MAX_RATIO") ? (size_t)atol(getenv("MHX_PINFLATE_MAX_RATIO")) : 16;
+    const size_t max_ratio = getenv("MHX_PINFLATE_MAX_RATIO") ? (size_t)atol(getenv("MHX_PINFLATE_MAX_RATIO")) : 16;
     const size_t seg_limit = std::max<size_t>(comp_bytes * max_ratio, (size_t)8 << 20);
     static const char *const too_much = "compression ratio beyond the multi-threaded decoder's memory bound";
     for (;;) {
@@ -473,13 +473,13 @@ bool ParallelGunzip::start(const uint8_t *z, size_t n, int threads, size_t min_b
     p.nthreads = threads;
     p.deflate_off = member_header_len(z, n);
     // small inputs: the sequential decoder is as fast (MHX_PINFLATE_MIN / MHX_PINFLATE_SEGMENT: test knobs)
-    static const size_t min_env = getenv("MHX_PINFLATE_MIN") ? (size_t)atol(getenv("MHX_PINFLATE_MIN")) : 0;
+    const size_t min_env = getenv("MHX_PINFLATE_MIN") ? (size_t)atol(getenv("MHX_PINFLATE_MIN")) : 0;
     const size_t min_bytes = min_env ? min_env : (min_bytes_arg ? min_bytes_arg : (8u << 20));
     if (!p.deflate_off || threads < 2 || n < min_bytes) return false;
     // segment targets: equal shares of the compressed bytes, ~1 MiB each (small segments keep the working set of a worker
     // -- 16-bit symbols plus bytes of ~10 MB of output -- near the caches and let the buffer pool recycle early), at least
     // two per thread
-    static const size_t seg_env = getenv("MHX_PINFLATE_SEGMENT") ? (size_t)atol(getenv("MHX_PINFLATE_SEGMENT")) : 0;
+    const size_t seg_env = getenv("MHX_PINFLATE_SEGMENT") ? (size_t)atol(getenv("MHX_PINFLATE_SEGMENT")) : 0;
     const size_t seg_bytes = seg_env ? seg_env : (seg_bytes_arg ? seg_bytes_arg : (1u << 20));
     size_t nseg = std::max<size_t>((size_t)threads * 2, n / seg_bytes);
     if (nseg > 65536) nseg = 65536;
