@@ -73,6 +73,27 @@ struct SlabMergeArgs {
     uint64_t *stats;
 };
 hipError_t launch_slab_insert(const SlabMergeArgs &a, uint64_t max_n, hipStream_t st);
+
+// sharded path, the usual case: the gathered slabs are binned by value and merged bin by bin in LDS (mhx_merge.hip)
+constexpr uint32_t kMergeMaxBins = 16384, kMergeMaxSlots = 4096; // LDS: 2 x 4 bytes per bin in the scatter pass, 12 per slot in the bin pass
+struct MergeArgs {
+    const uint64_t *slabs;      // device: nranks slabs of slab_words 8-byte words each: hashes[cap] | counts u32[cap]
+    uint64_t slab_words, cap;
+    uint64_t n[kMaxMergeRanks]; // valid entries of each slab
+    uint32_t nranks;
+    uint32_t min_mult;
+    uint64_t t_min;
+    uint32_t shift;             // bin of a hash = hash >> shift (< nbins for every hash <= t_min)
+    uint32_t nbins;             // power of two, 256 .. kMergeMaxBins
+    uint32_t region;            // entries a bin's region holds
+    uint32_t table_slots;       // LDS table of merge_bin_kernel (power of two, >= 4/3 region)
+    uint32_t *cursor;           // [nbins] entries placed per bin; zero between merges (merge_bin_kernel clears it)
+    uint32_t *qn;               // [nbins] qualifying entries per bin
+    uint32_t *flags;            // [0]: 1 a region overflowed, 2 a table overflowed, 4 too many qualifying entries in a bin; zero between merges
+    uint64_t *sc_keys;          // [nbins * region]
+    uint32_t *sc_cnts;          // [nbins * region]
+};
+hipError_t launch_merge_bins(const MergeArgs &a, uint64_t max_n, uint64_t *out, uint32_t out_cap, hipStream_t st);
 bool hash_k_supported(int k);
 
 // FASTA on the device (mhx_fasta.hip): raw file bytes -> dense sequence stream + record separator positions.
@@ -96,8 +117,14 @@ struct DistArgs {
 hipError_t launch_dist_pairs(const DistArgs &a, hipStream_t st);
 
 // all-vs-refs fast path (nr <= 32): value-range partition + LDS hash probe
-constexpr int kDistRanges = 1024;     // value ranges the hash space is cut into
-constexpr int kDistTableSlots = 2048; // LDS table of one range (refs' hashes of that range)
+#ifndef MHX_DIST_RANGES
+#define MHX_DIST_RANGES 1024
+#endif
+#ifndef MHX_DIST_SLOTS
+#define MHX_DIST_SLOTS 2048
+#endif
+constexpr int kDistRanges = MHX_DIST_RANGES;     // value ranges the hash space is cut into
+constexpr int kDistTableSlots = MHX_DIST_SLOTS; // LDS table of one range (refs' hashes of that range)
 #ifndef MHX_DIST_QCHUNKS
 #define MHX_DIST_QCHUNKS 4
 #endif

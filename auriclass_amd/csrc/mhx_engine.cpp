@@ -80,6 +80,14 @@ extern "C" void mhx_shutdown(void)
     hipFree(g.fasta.d_raw); hipFree(g.fasta.d_out); hipFree(g.fasta.d_ws); hipFree(g.fasta.d_seps);
     if (g.fasta.h_words) hipHostFree(g.fasta.h_words);
     hipFree(g.dist_ws);
+    hipFree(g.dist_in);
+    for (void *p : g.ingest_pinned) hipHostFree(p);
+    for (int i = 0; i < 2; ++i) {
+        hipFree(g.ingest_slot[i]);
+        if (g.ingest_copied[i]) hipEventDestroy(g.ingest_copied[i]);
+        if (g.ingest_consumed[i]) hipEventDestroy(g.ingest_consumed[i]);
+    }
+    if (g.ingest_word) hipHostFree(g.ingest_word);
     if (g.copy_stream) hipStreamSynchronize(g.copy_stream);
     for (int i = 0; i < Engine::kPinnedSlots; ++i) {
         if (g.pinned[i]) hipHostFree(g.pinned[i]);
@@ -157,6 +165,12 @@ struct mhx_sketcher {
     bool merged = false;       // merge_slabs has added other shards' entries to the table: reset before the next push
     uint64_t *d_merge_in = nullptr; // staging of gathered slabs that arrive in host memory (gloo)
     size_t merge_in_cap = 0;
+    // workspace of the binned merge (mhx_merge.hip): per-bin cursors / counts / flags (kept zero between merges by the
+    // kernels), bin regions
+    uint32_t *d_mg_small = nullptr;  // [kMergeMaxBins] cursor | [kMergeMaxBins] qn | [16] flags
+    uint64_t *d_mg_keys = nullptr;
+    uint32_t *d_mg_cnts = nullptr;
+    size_t mg_entries = 0;
     // finish(): one device block [n, T, flags, #(2^64-1) | hashes[fin_cap] | counts[fin_cap]] and its pinned host
     // mirror, so the result comes back in ONE copy (five separate copies cost 20-60 us of idle gap each)
     uint64_t *d_fin = nullptr, *h_fin = nullptr;
@@ -209,7 +223,7 @@ static void free_sketcher(mhx_sketcher *sk)
     hipFree(sk->d_keys); hipFree(sk->d_cnts); hipFree(sk->d_thresh); hipFree(sk->d_hist); hipFree(sk->d_acc);
     hipFree(sk->d_stats); hipFree(sk->d_tickets); hipFree(sk->d_done); hipFree(sk->d_need); hipFree(sk->d_phase_rec); hipFree(sk->d_tile_state); hipFree(sk->d_stage);
     hipFree(sk->d_out_keys); hipFree(sk->d_out_cnts); hipFree(sk->d_out_n);
-    hipFree(sk->d_exp_hdr); hipFree(sk->d_merge_in);
+    hipFree(sk->d_exp_hdr); hipFree(sk->d_merge_in); hipFree(sk->d_mg_small); hipFree(sk->d_mg_keys); hipFree(sk->d_mg_cnts);
     if (sk->h_exp_hdr) hipHostFree(sk->h_exp_hdr);
     hipFree(sk->d_fin);
     hipFree(sk->d_fin_ordered);
@@ -388,6 +402,21 @@ static int settle(mhx_sketcher *sk)
         HIPCHK(hipStreamSynchronize(g.stream));
     }
     sk->unsettled.clear();
+    return MHX_OK;
+}
+
+int sketcher_release_oldest_push(mhx_sketcher *sk, hipStream_t side, uint32_t *word)
+{
+    if (!sk || sk->unsettled.empty()) return MHX_OK;
+    HIPCHK(hipMemcpyAsync(word, sk->d_need, sizeof(uint32_t), hipMemcpyDeviceToHost, side));
+    HIPCHK(hipStreamSynchronize(side));
+    if (*word == 0) {
+        sk->unsettled.erase(sk->unsettled.begin());
+        return MHX_OK;
+    }
+    int rc = repair_unsettled(sk); // reads every unsettled span again: all of them are still in place
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
     return MHX_OK;
 }
 
@@ -1008,6 +1037,82 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
     if (rc) return rc;
     if ((others || n_ranks > 1) && !slabs) return fail(MHX_E_ARG, "null slabs");
     const uint64_t slab_words = cap_entries + cap_entries / 2;
+    const uint64_t *d_slabs = (const uint64_t *)slabs;
+    if (!slabs_on_device && (others || headers[8 * (size_t)own_rank])) {
+        const size_t bytes = (size_t)n_ranks * slab_words * sizeof(uint64_t);
+        if (sk->merge_in_cap < bytes) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            hipFree(sk->d_merge_in);
+            sk->d_merge_in = nullptr;
+            sk->merge_in_cap = 0;
+            const size_t cap = (bytes + bytes / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+            HIPCHK(hipMalloc((void **)&sk->d_merge_in, cap));
+            sk->merge_in_cap = cap;
+        }
+        HIPCHK(hipMemcpyAsync(sk->d_merge_in, slabs, bytes, hipMemcpyHostToDevice, g.stream));
+        d_slabs = sk->d_merge_in;
+    }
+    sk->merged = true;
+    // The usual case: all slabs (this rank's own among them) are binned by value and merged bin by bin in LDS; the result
+    // lands in the pinned block in hash order.  Non-uniform data (a bin overflows), more than 64 ranks or more than ~16 M
+    // entries take the table path below.
+    static const bool force_table = getenv("MHX_MERGE_TABLE") != nullptr;
+    const uint64_t total = others + headers[8 * (size_t)own_rank];
+    if (!force_table && n_ranks <= kMaxMergeRanks && total > 0 && total <= (uint64_t)kMergeMaxBins * 1024) {
+        uint32_t nbins = 256;
+        while ((uint64_t)nbins * 1024 < total) nbins <<= 1;
+        const uint32_t lg = (uint32_t)__builtin_ctz(nbins);
+        const uint32_t bits = 64u - (uint32_t)__builtin_clzll(t_min | 1ull);
+        MergeArgs a;
+        a.shift = bits > lg ? bits - lg : 0u;
+        const uint64_t bins_used = (t_min >> a.shift) + 1;
+        const double avg = (double)total / (double)bins_used;
+        a.region = (uint32_t)(avg + 6.0 * sqrt(avg) + 64.0);
+        a.table_slots = 256;
+        while ((uint64_t)a.table_slots * 3 / 4 < a.region) a.table_slots <<= 1;
+        if (a.table_slots <= kMergeMaxSlots) {
+            if (!sk->d_mg_small) {
+                HIPCHK(hipMalloc((void **)&sk->d_mg_small, (2 * (size_t)kMergeMaxBins + 16) * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(sk->d_mg_small, 0, (2 * (size_t)kMergeMaxBins + 16) * sizeof(uint32_t), g.stream));
+            }
+            const size_t need = (size_t)nbins * a.region;
+            if (sk->mg_entries < need) {
+                HIPCHK(hipStreamSynchronize(g.stream));
+                hipFree(sk->d_mg_keys); hipFree(sk->d_mg_cnts);
+                sk->d_mg_keys = nullptr; sk->d_mg_cnts = nullptr;
+                sk->mg_entries = 0;
+                const size_t want = need + need / 4;
+                HIPCHK(hipMalloc((void **)&sk->d_mg_keys, want * sizeof(uint64_t)));
+                HIPCHK(hipMalloc((void **)&sk->d_mg_cnts, want * sizeof(uint32_t)));
+                sk->mg_entries = want;
+            }
+            a.slabs = d_slabs; a.slab_words = slab_words; a.cap = cap_entries; a.nranks = n_ranks; a.min_mult = sk->m; a.t_min = t_min; a.nbins = nbins;
+            uint64_t max_all = 0;
+            for (uint32_t r = 0; r < kMaxMergeRanks; ++r) { a.n[r] = r < n_ranks ? headers[8 * (size_t)r] : 0; max_all = a.n[r] > max_all ? a.n[r] : max_all; }
+            a.cursor = sk->d_mg_small; a.qn = sk->d_mg_small + kMergeMaxBins; a.flags = sk->d_mg_small + 2 * kMergeMaxBins;
+            a.sc_keys = sk->d_mg_keys; a.sc_cnts = sk->d_mg_cnts;
+            HIPCHK(launch_merge_bins(a, max_all, sk->h_fin, sk->fin_cap, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+            const uint64_t *h = sk->h_fin;
+            const uint64_t n_q = h[0];
+            if (h[2] == 0 && n_q <= sk->fin_cap) {
+                const uint64_t maxkey_all = maxkey_others + headers[8 * (size_t)own_rank + 3];
+                const bool extra = t_min == ~0ull && maxkey_all >= sk->m; // the one hash value no table holds
+                const uint64_t n_src = n_q + (extra ? 1 : 0);
+                if (n_src < sk->s && t_min < sk->hash_max)
+                    return fail(MHX_E_CAPACITY, "sharded sketch not exact: %llu of %u entries with multiplicity >= %u below the smallest shard threshold; "
+                                "every rank must sketch its shard again with a larger budget_scale", (unsigned long long)n_src, sk->s, sk->m);
+                const uint32_t nn = n_src < sk->s ? (uint32_t)n_src : sk->s;
+                const uint32_t from_block = nn < n_q ? nn : (uint32_t)n_q;
+                memcpy(hashes, h + 4, (size_t)from_block * sizeof(uint64_t));
+                if (counts) memcpy(counts, reinterpret_cast<const uint32_t *>(h + 4 + sk->fin_cap), (size_t)from_block * sizeof(uint32_t));
+                if (nn > from_block) { hashes[from_block] = ~0ull; if (counts) counts[from_block] = maxkey_all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)maxkey_all; }
+                *n_out = nn;
+                return MHX_OK;
+            }
+            // (flags raised or more qualifying entries than the block holds: the table path decides)
+        }
+    }
     const uint64_t occupied = headers[8 * (size_t)own_rank + 4];
     if (occupied + others > sk->nslots / 2) {
         // The other shards' entries would crowd this table (tiny tables of tiny inputs, or shards that never tightened
@@ -1034,22 +1139,6 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
         sk->merged = true;
         return mhx_merge_shard_partials(ah.data(), ac.data(), an.data(), at.data(), n_ranks, sk->k, sk->s, sk->m, hashes, counts, n_out);
     }
-    const uint64_t *d_slabs = (const uint64_t *)slabs;
-    if (!slabs_on_device && others) {
-        const size_t bytes = (size_t)n_ranks * slab_words * sizeof(uint64_t);
-        if (sk->merge_in_cap < bytes) {
-            HIPCHK(hipStreamSynchronize(g.stream));
-            hipFree(sk->d_merge_in);
-            sk->d_merge_in = nullptr;
-            sk->merge_in_cap = 0;
-            const size_t cap = (bytes + bytes / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
-            HIPCHK(hipMalloc((void **)&sk->d_merge_in, cap));
-            sk->merge_in_cap = cap;
-        }
-        HIPCHK(hipMemcpyAsync(sk->d_merge_in, slabs, bytes, hipMemcpyHostToDevice, g.stream));
-        d_slabs = sk->d_merge_in;
-    }
-    sk->merged = true;
     for (uint32_t r0 = 0; r0 < n_ranks; r0 += kMaxMergeRanks) { // (one launch for up to 64 ranks)
         SlabMergeArgs a;
         a.slabs = d_slabs + (size_t)r0 * slab_words;
@@ -1152,6 +1241,23 @@ extern "C" int mhx_merge_shard_partials(const uint64_t *hashes, const uint32_t *
 // ---- batched distance ------------------------------------------------------------------
 extern "C" double mhx_last_dist_kernel_ms(void) { return g.last_dist_ms; }
 
+// Persistent device staging of the host-pointer form (one buffer, grown on demand): six hipMalloc / hipFree pairs per
+// call cost more than the kernels of an AuriClass-sized comparison (1 query x 24 references).
+static int dist_stage(size_t bytes, uint8_t **out)
+{
+    if (g.dist_in_cap < bytes) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        hipFree(g.dist_in);
+        g.dist_in = nullptr;
+        g.dist_in_cap = 0;
+        const size_t cap = (bytes + bytes / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+        if (hipMalloc((void **)&g.dist_in, cap) != hipSuccess) return fail(MHX_E_HIP, "hipMalloc failed in dist_batch (%zu bytes)", cap);
+        g.dist_in_cap = cap;
+    }
+    *out = g.dist_in;
+    return MHX_OK;
+}
+
 extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r, const uint32_t *r_len,
                               uint32_t nr, uint32_t stride, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist,
                               int device_ptrs)
@@ -1166,62 +1272,99 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
     if (pairs > 0x7FFFFFFFull) return fail(MHX_E_ARG, "too many pairs for one call");
     DistArgs a;
     a.nq = nq; a.nr = nr; a.stride = stride; a.s = s; a.k = k; a.out_stride = nr; a.out_off = 0;
-    void *dq = nullptr, *dr = nullptr, *dql = nullptr, *drl = nullptr, *dc = nullptr, *dd = nullptr, *dx = nullptr;
-    auto cleanup = [&]() { hipFree(dq); hipFree(dr); hipFree(dql); hipFree(drl); hipFree(dc); hipFree(dd); hipFree(dx); };
+    uint32_t *dc = nullptr, *dd = nullptr;
     if (device_ptrs) {
         a.q = q; a.q_len = q_len; a.r = r; a.r_len = r_len; a.common = common; a.denom = denom; a.dist = dist;
     } else {
         for (uint32_t i = 0; i < nq; ++i) if (q_len[i] > stride) return fail(MHX_E_ARG, "q_len[%u] exceeds stride", i);
         for (uint32_t i = 0; i < nr; ++i) if (r_len[i] > stride) return fail(MHX_E_ARG, "r_len[%u] exceeds stride", i);
-        hipError_t e = hipSuccess;
-        auto A = [&](void **p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
-        A(&dq, (size_t)nq * stride * 8); A(&dr, (size_t)nr * stride * 8); A(&dql, (size_t)nq * 4); A(&drl, (size_t)nr * 4);
-        A(&dc, pairs * 4); A(&dd, pairs * 4);
-        if (e != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "hipMalloc failed in dist_batch: %s", hipGetErrorString(e)); }
-        hipError_t ce = hipMemcpyAsync(dq, q, (size_t)nq * stride * 8, hipMemcpyHostToDevice, g.stream);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(dr, r, (size_t)nr * stride * 8, hipMemcpyHostToDevice, g.stream);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t bq = up((size_t)nq * stride * 8), br = up((size_t)nr * stride * 8), bql = up((size_t)nq * 4), brl = up((size_t)nr * 4), bo = up(pairs * 4);
+        uint8_t *base = nullptr;
+        rc = dist_stage(bq + br + bql + brl + 2 * bo, &base);
+        if (rc) return rc;
+        uint8_t *dq = base, *dr = dq + bq, *dql = dr + br, *drl = dql + bql;
+        dc = (uint32_t *)(drl + brl);
+        dd = (uint32_t *)(drl + brl + bo);
+        // rows that are mostly padding travel one by one (valid prefix only), full ones as one block
+        hipError_t ce = hipSuccess;
+        auto rows = [&](uint8_t *dst, const uint64_t *src, const uint32_t *len, uint32_t n) {
+            uint64_t valid = 0;
+            for (uint32_t i = 0; i < n; ++i) valid += len[i];
+            if (n > 64 || valid * 2 >= (uint64_t)n * stride) {
+                if (ce == hipSuccess) ce = hipMemcpyAsync(dst, src, (size_t)n * stride * 8, hipMemcpyHostToDevice, g.stream);
+                return;
+            }
+            for (uint32_t i = 0; i < n && ce == hipSuccess; ++i)
+                if (len[i]) ce = hipMemcpyAsync(dst + (size_t)i * stride * 8, src + (size_t)i * stride, (size_t)len[i] * 8, hipMemcpyHostToDevice, g.stream);
+        };
+        rows(dq, q, q_len, nq);
+        rows(dr, r, r_len, nr);
         if (ce == hipSuccess) ce = hipMemcpyAsync(dql, q_len, (size_t)nq * 4, hipMemcpyHostToDevice, g.stream);
         if (ce == hipSuccess) ce = hipMemcpyAsync(drl, r_len, (size_t)nr * 4, hipMemcpyHostToDevice, g.stream);
-        if (ce != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "H2D copy failed in dist_batch: %s", hipGetErrorString(ce)); }
+        if (ce != hipSuccess) return fail(MHX_E_HIP, "H2D copy failed in dist_batch: %s", hipGetErrorString(ce));
         a.q = (const uint64_t *)dq; a.q_len = (const uint32_t *)dql; a.r = (const uint64_t *)dr; a.r_len = (const uint32_t *)drl;
-        a.common = (uint32_t *)dc; a.denom = (uint32_t *)dd; a.dist = nullptr; // distances in host libm below
+        a.common = dc; a.denom = dd; a.dist = nullptr; // distances in host libm below
     }
-    // all-vs-refs fast path: the references go through in slices of 32 (one bit each in the range kernel's
-    // masks), every slice filling its columns of the [nq][nr] outputs; the generic pair-per-workgroup kernel
-    // serves tiny batches and is the fallback of a slice whose value ranges are too uneven for the LDS table
+    // all-vs-refs fast path: the references go through in slices of 32 (one bit each in the range kernel's masks), the
+    // queries in batches (MHX_DIST_QBATCH; default: all at once), every (batch, slice) filling its block of the [nq][nr]
+    // outputs; the generic pair-per-workgroup kernel serves tiny batches and is the fallback of a block whose value
+    // ranges are too uneven for the LDS table.  Nothing is read back between the blocks: every block has its own flag
+    // word, all of them come back with ONE copy behind the last launch.
     const bool fast = pairs >= 64 && getenv("MHX_DIST_GENERIC") == nullptr;
+    uint32_t qbatch = nq;
+    if (const char *e = getenv("MHX_DIST_QBATCH")) { const long v = atol(e); if (v > 0 && (uint64_t)v < nq) qbatch = (uint32_t)v; }
+    const uint32_t nslices = (nr + 31) / 32, nbatches = (nq + qbatch - 1) / qbatch, nblocks = nslices * nbatches;
     DistWork w{};
+    uint32_t *d_params = nullptr;
     if (fast) {
+        if (nblocks > 4096) return fail(MHX_E_ARG, "too many (query batch, reference slice) blocks in one call");
         size_t oq, orr, oc, op;
-        const size_t need = dist_work_bytes(nq, nr < 32 ? nr : 32, &oq, &orr, &oc, &op);
+        const size_t need = dist_work_bytes(qbatch, nr < 32 ? nr : 32, &oq, &orr, &oc, &op) + (size_t)nblocks * 8;
         if (g.dist_ws_cap < need) {
+            HIPCHK(hipStreamSynchronize(g.stream));
             hipFree(g.dist_ws);
             g.dist_ws = nullptr;
             g.dist_ws_cap = 0;
-            if (hipMalloc((void **)&g.dist_ws, need) != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "hipMalloc failed for the distance workspace"); }
+            if (hipMalloc((void **)&g.dist_ws, need) != hipSuccess) return fail(MHX_E_HIP, "hipMalloc failed for the distance workspace");
             g.dist_ws_cap = need;
         }
         w.offs_q = (uint32_t *)(g.dist_ws + oq); w.offs_r = (uint32_t *)(g.dist_ws + orr);
-        w.cpart = g.dist_ws + oc; w.params = (uint32_t *)(g.dist_ws + op);
+        w.cpart = g.dist_ws + oc;
+        d_params = (uint32_t *)(g.dist_ws + op); // [block][2]: shift, overflow flag
     }
+    auto block_args = [&](uint32_t b) {
+        const uint32_t q0 = (b / nslices) * qbatch, r0 = (b % nslices) * 32;
+        DistArgs x = a;
+        x.q = a.q + (uint64_t)q0 * stride;
+        x.q_len = a.q_len + q0;
+        x.nq = nq - q0 < qbatch ? nq - q0 : qbatch;
+        x.r = a.r + (uint64_t)r0 * stride;
+        x.r_len = a.r_len + r0;
+        x.nr = nr - r0 < 32 ? nr - r0 : 32;
+        x.common = a.common + (uint64_t)q0 * nr;
+        x.denom = a.denom + (uint64_t)q0 * nr;
+        x.dist = a.dist ? a.dist + (uint64_t)q0 * nr : nullptr;
+        x.out_off = r0;
+        return x;
+    };
     hipEventRecord(g.ev0, g.stream);
     hipError_t le = hipSuccess;
     if (!fast) le = launch_dist_pairs(a, g.stream);
-    for (uint32_t r0 = 0; fast && r0 < nr && le == hipSuccess; r0 += 32) {
-        DistArgs slice = a;
-        slice.r = a.r + (uint64_t)r0 * stride;
-        slice.r_len = a.r_len + r0;
-        slice.nr = nr - r0 < 32 ? nr - r0 : 32;
-        slice.out_off = r0;
-        le = launch_dist_ranges(slice, w, g.stream);
-        if (le != hipSuccess) break;
-        uint32_t flag = 0;
-        hipMemcpyAsync(&flag, w.params + 1, 4, hipMemcpyDeviceToHost, g.stream);
-        hipStreamSynchronize(g.stream);
-        if (flag) le = launch_dist_pairs(slice, g.stream); // a value range overflowed the LDS table
+    for (uint32_t b = 0; fast && b < nblocks && le == hipSuccess; ++b) {
+        w.params = d_params + 2 * b;
+        le = launch_dist_ranges(block_args(b), w, g.stream);
+    }
+    if (fast && le == hipSuccess) {
+        std::vector<uint32_t> flags((size_t)nblocks * 2);
+        if (hipMemcpyAsync(flags.data(), d_params, flags.size() * 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+            hipStreamSynchronize(g.stream) != hipSuccess)
+            return fail(MHX_E_HIP, "dist kernel failed");
+        for (uint32_t b = 0; b < nblocks && le == hipSuccess; ++b)
+            if (flags[2 * b + 1]) le = launch_dist_pairs(block_args(b), g.stream); // a value range overflowed the LDS table
     }
     hipEventRecord(g.ev1, g.stream);
-    if (le != hipSuccess) { cleanup(); return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le)); }
+    if (le != hipSuccess) return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le));
     hipError_t se = hipSuccess;
     if (!device_ptrs) {
         se = hipMemcpyAsync(common, dc, pairs * 4, hipMemcpyDeviceToHost, g.stream);
@@ -1231,7 +1374,6 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
     float ms = 0.f;
     hipEventElapsedTime(&ms, g.ev0, g.ev1);
     g.last_dist_ms = ms;
-    cleanup();
     if (se != hipSuccess) return fail(MHX_E_HIP, "dist kernel failed: %s", hipGetErrorString(se));
     if (!device_ptrs && dist) {
         for (uint64_t i = 0; i < pairs; ++i) {

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -39,17 +41,32 @@ struct Engine {
     double last_dist_ms = 0.0;
     uint8_t *dist_ws = nullptr; // workspace of the all-vs-refs distance path
     size_t dist_ws_cap = 0;
+    uint8_t *dist_in = nullptr; // staging of a host-pointer distance batch (rows, lengths, outputs)
+    size_t dist_in_cap = 0;
     // bulk file ingest: pinned staging ring + copy stream (allocated on first use, kept)
     static constexpr int kPinnedSlots = 4;
     uint8_t *pinned[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pinned_free[kPinnedSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     FastaCtx fasta;
+    // chunked ingest (.gz FASTQ): pinned host buffers kept between calls, two device slots with their events, a pinned word
+    static constexpr size_t kIngestPinnedKeep = 12;
+    std::vector<void *> ingest_pinned;
+    uint8_t *ingest_slot[2] = {nullptr, nullptr};
+    hipEvent_t ingest_copied[2] = {nullptr, nullptr}, ingest_consumed[2] = {nullptr, nullptr};
+    uint32_t *ingest_word = nullptr;
 };
 extern Engine g;
 int require_engine();
 
 } // namespace mhx
+
+// FASTQ pushes stay "unsettled" (their bytes may be read again by a repair pass) until a synchronisation point.  A caller
+// that recycles its device buffers push by push (the chunked ingest) asks here whether the OLDEST unsettled push, whose
+// kernels it knows to have completed, can be let go: the "repair due" word is read on `side` (not behind the kernels of
+// later pushes on the engine stream) into the pinned `word`; still zero -> that push needs no repair and is forgotten;
+// set -> everything unsettled is repaired now, while all of it is still intact (full synchronisation).
+int sketcher_release_oldest_push(mhx_sketcher *sk, hipStream_t side, uint32_t *word);
 
 // sketcher with `table_scale` times the default candidate table and admission budget
 int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint64_t table_scale, mhx_sketcher **out);

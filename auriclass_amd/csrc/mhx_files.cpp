@@ -113,14 +113,85 @@ static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t
 namespace {
 constexpr size_t kIngestChunk = 32u << 20;
 
+// Host buffers of the chunk pipeline.  Pinned (hipHostMalloc) when possible: the copy to the device then runs at the
+// link's rate on the copy stream while the host thread goes on, instead of being staged through the runtime's bounce
+// buffer.  Pinning 32 MiB costs milliseconds, so the engine keeps the buffers between calls (Engine::ingest_pinned);
+// at most `limit` are in use per call, producers wait for one to come back.
+struct HostBuf {
+    uint8_t *p = nullptr;
+    bool pinned = false;
+};
+
+class BufPool {
+  public:
+    BufPool(size_t bytes, size_t limit) : bytes_(bytes), limit_(limit) {}
+    ~BufPool()
+    {
+        for (auto &b : spare_) {
+            if (b.pinned && g.ready && g.ingest_pinned.size() < Engine::kIngestPinnedKeep) g.ingest_pinned.push_back(b.p);
+            else if (b.pinned) hipHostFree(b.p);
+            else free(b.p);
+        }
+    }
+    HostBuf take()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            if (!spare_.empty()) { HostBuf b = spare_.back(); spare_.pop_back(); return b; }
+            if (allocated_ < limit_ || abort_) break; // (after an abort nobody gives buffers back: let the producer run out)
+            cv_.wait(lk);
+        }
+        ++allocated_;
+        if (!g.ingest_pinned.empty()) { HostBuf b{(uint8_t *)g.ingest_pinned.back(), true}; g.ingest_pinned.pop_back(); return b; }
+        lk.unlock();
+        HostBuf b;
+        static const bool no_pin = getenv("MHX_INGEST_PAGEABLE") != nullptr;
+        (void)hipSetDevice(g.device); // producers are threads of their own
+        if (!no_pin && hipHostMalloc((void **)&b.p, bytes_, hipHostMallocDefault) == hipSuccess) b.pinned = true;
+        else { (void)hipGetLastError(); b.p = (uint8_t *)malloc(bytes_); b.pinned = false; }
+        if (!b.p) throw std::bad_alloc();
+        return b;
+    }
+    void give(HostBuf b)
+    {
+        if (!b.p) return;
+        { std::lock_guard<std::mutex> lk(m_); spare_.push_back(b); }
+        cv_.notify_one();
+    }
+    void abort() { { std::lock_guard<std::mutex> lk(m_); abort_ = true; } cv_.notify_all(); }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<HostBuf> spare_;
+    size_t bytes_, limit_, allocated_ = 0;
+    bool abort_ = false;
+};
+
 // One record-aligned piece of an inflated FASTQ.  The buffer keeps GzInflater::kWindow bytes of room in
 // front of the data: the previous 32 KiB of the stream, which DEFLATE matches may still refer to.
 struct IngestChunk {
-    std::unique_ptr<uint8_t[]> buf; // kWindow + kIngestChunk + slack bytes, not zero-filled
+    HostBuf buf;           // kWindow + kIngestChunk + slack bytes, not zero-filled; goes back to `pool` with the chunk
+    BufPool *pool = nullptr;
     size_t size = 0;
     int file = 0;
     bool first_of_file = false;
-    uint8_t *data() { return buf.get() + GzInflater::kWindow; }
+    IngestChunk() = default;
+    IngestChunk(const IngestChunk &) = delete;
+    IngestChunk &operator=(const IngestChunk &) = delete;
+    IngestChunk(IngestChunk &&o) noexcept { *this = std::move(o); }
+    IngestChunk &operator=(IngestChunk &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            buf = o.buf; pool = o.pool; size = o.size; file = o.file; first_of_file = o.first_of_file;
+            o.buf = HostBuf(); o.pool = nullptr;
+        }
+        return *this;
+    }
+    ~IngestChunk() { release(); }
+    void release() { if (pool && buf.p) pool->give(buf); buf = HostBuf(); }
+    uint8_t *data() { return buf.p + GzInflater::kWindow; }
     static size_t alloc_bytes() { return GzInflater::kWindow + kIngestChunk + GzInflater::kOvershoot + 64; }
 };
 
@@ -144,26 +215,19 @@ class ChunkQueue {
         room_.notify_one();
         return true;
     }
-    // chunk buffers go round: fresh 32 MiB allocations cost more in page faults than the inflate that fills them
-    std::unique_ptr<uint8_t[]> take_buffer()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (!spare_.empty()) { std::unique_ptr<uint8_t[]> b = std::move(spare_.back()); spare_.pop_back(); return b; }
-        }
-        return std::unique_ptr<uint8_t[]>(new uint8_t[IngestChunk::alloc_bytes()]);
-    }
-    void give_back(std::unique_ptr<uint8_t[]> b) { if (b) { std::lock_guard<std::mutex> lk(m_); spare_.push_back(std::move(b)); } }
+    // chunk buffers go round (BufPool): fresh 32 MiB allocations cost more in page faults than the inflate that fills them
+    explicit ChunkQueue(size_t max_buffers) : pool_(IngestChunk::alloc_bytes(), max_buffers) {}
+    void take_buffer(IngestChunk &c) { c.release(); c.buf = pool_.take(); c.pool = &pool_; }
     void producer_started() { std::lock_guard<std::mutex> lk(m_); ++live_; }
     void producer_done() { std::lock_guard<std::mutex> lk(m_); --live_; ready_.notify_all(); }
-    void abort() { std::lock_guard<std::mutex> lk(m_); abort_ = true; room_.notify_all(); }
+    void abort() { { std::lock_guard<std::mutex> lk(m_); abort_ = true; room_.notify_all(); } pool_.abort(); }
     bool aborted() { std::lock_guard<std::mutex> lk(m_); return abort_; }
 
   private:
     std::mutex m_;
     std::condition_variable ready_, room_;
     std::deque<IngestChunk> q_;
-    std::vector<std::unique_ptr<uint8_t[]>> spare_;
+    BufPool pool_;
     int live_ = 0;
     bool abort_ = false;
 };
@@ -333,7 +397,7 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
         IngestChunk c;
         c.file = file;
         c.first_of_file = first;
-        c.buf = q->take_buffer();
+        q->take_buffer(c);
         uint8_t *d = c.data();
         if (!tail.empty()) memcpy(d + carry_len - tail.size(), tail.data(), tail.size());
         t_alloc += secs(t0, now());
@@ -635,13 +699,23 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         bf.head.clear();
         resident.push_back(std::move(bf));
     }
-    // 2. compressed files: one inflate thread per file, 32 MiB record-aligned chunks
-    uint8_t *d_slot = nullptr;
-    if (!rc && !fallback && !queued.empty() && hipMalloc((void **)&d_slot, kIngestChunk + GzInflater::kOvershoot + 64) != hipSuccess)
-        rc = fail(MHX_E_HIP, "hipMalloc failed for the ingest slot");
+    // 2. compressed files: one inflate thread per file (each with its share of decoding threads), 32 MiB record-aligned
+    // chunks in pinned buffers; TWO device slots: chunk j is copied on the copy stream while chunk j - 1 is being parsed
+    // and hashed on the engine stream.  A slot is overwritten only when the kernels of its previous chunk have completed
+    // (event) AND that chunk is known to need no repair pass (sketcher_release_oldest_push) -- no whole-stream
+    // synchronisation per chunk.
     std::vector<FileIngestState> st(n_paths);
     if (!rc && !fallback && !queued.empty()) {
-        ChunkQueue q;
+        for (int i = 0; i < 2 && !rc; ++i) {
+            if (!g.ingest_slot[i] && hipMalloc((void **)&g.ingest_slot[i], kIngestChunk + GzInflater::kOvershoot + 64) != hipSuccess) rc = fail(MHX_E_HIP, "hipMalloc failed for the ingest slot");
+            if (!rc && !g.ingest_copied[i] && hipEventCreateWithFlags(&g.ingest_copied[i], hipEventDisableTiming) != hipSuccess) rc = fail(MHX_E_HIP, "event creation failed");
+            if (!rc && !g.ingest_consumed[i] && hipEventCreateWithFlags(&g.ingest_consumed[i], hipEventDisableTiming) != hipSuccess) rc = fail(MHX_E_HIP, "event creation failed");
+        }
+        if (!rc && !g.ingest_word && hipHostMalloc((void **)&g.ingest_word, 64, hipHostMallocDefault) != hipSuccess) rc = fail(MHX_E_HIP, "hipHostMalloc failed");
+        if (!rc && !g.copy_stream && hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(MHX_E_HIP, "stream creation failed");
+    }
+    if (!rc && !fallback && !queued.empty()) {
+        ChunkQueue q(2 * queued.size() + 4);
         std::vector<std::thread> threads;
         for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
         // decoding threads per .gz file: the host's share (ingest_thread_budget: MHX_INGEST_THREADS, else the cores this
@@ -649,23 +723,43 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         const int budget = ingest_thread_budget();
         const int per_file = std::max(1, budget / (int)std::max<size_t>(1, queued.size()) - 1);
         for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, per_file, &q, &st[i]);
-        IngestChunk c;
+        IngestChunk c, in_flight[2]; // in_flight[slot]: the host buffer whose copy into that slot may still be running
+        uint64_t nchunk = 0;
+        auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) { rc = fail(MHX_E_HIP, "%s failed: %s", what, hipGetErrorString(e)); q.abort(); } return e == hipSuccess; };
         while (q.get(c)) {
             if (rc) continue; // drain
             if (c.first_of_file) header.offer(c.file, c.data(), std::min<size_t>(c.size, 1u << 20), k);
-            if (hipMemcpyAsync(d_slot, c.data(), c.size, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); q.abort(); continue; }
-            rc = mhx_sketcher_push_device(sk, d_slot, c.size, MHX_FMT_FASTQ4);
-            if (!rc) rc = mhx_sketcher_sync(sk); // the slot is overwritten next: the push (and a repair pass, if due) must be through
-            if (rc) q.abort();
-            else q.give_back(std::move(c.buf)); // the copy out of it has completed
+            const int slot = (int)(nchunk & 1);
+            if (nchunk >= 2) { // the slot's previous tenant (chunk nchunk - 2): kernels through, repair question settled
+                if (!hip_ok(hipEventSynchronize(g.ingest_consumed[slot]), "event wait")) continue;
+                rc = sketcher_release_oldest_push(sk, g.copy_stream, g.ingest_word);
+                if (rc) { q.abort(); continue; }
+            }
+            if (!hip_ok(hipMemcpyAsync(g.ingest_slot[slot], c.data(), c.size, hipMemcpyHostToDevice, g.copy_stream), "H2D copy")) continue;
+            if (!hip_ok(hipEventRecord(g.ingest_copied[slot], g.copy_stream), "event record")) continue;
+            if (!hip_ok(hipStreamWaitEvent(g.stream, g.ingest_copied[slot], 0), "stream wait")) continue;
+            rc = mhx_sketcher_push_device(sk, g.ingest_slot[slot], c.size, MHX_FMT_FASTQ4);
+            if (rc) { q.abort(); continue; }
+            if (!hip_ok(hipEventRecord(g.ingest_consumed[slot], g.stream), "event record")) continue;
+            // the host buffer goes back to the producers once its copy has completed: the one of the OTHER slot has had a
+            // whole chunk's time for that
+            if (in_flight[slot ^ 1].buf.p) {
+                if (!hip_ok(hipEventSynchronize(g.ingest_copied[slot ^ 1]), "event wait")) continue;
+                in_flight[slot ^ 1].release();
+            }
+            in_flight[slot] = std::move(c);
+            ++nchunk;
         }
+        if (hipStreamSynchronize(g.copy_stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "copy stream sync failed");
+        if (rc) hipStreamSynchronize(g.stream); // nothing may still read the slots or the buffers when we leave
+        in_flight[0].release();
+        in_flight[1].release();
         for (auto &t : threads) t.join();
     }
     bool own_failed = false;
     for (auto &f : st) own_failed = own_failed || f.own_inflate_failed;
     if (own_failed && !force_zlib) { // the engine's own decoder refused a stream: let zlib have the last word
-        hipFree(d_slot);
-        free_resident();
+            free_resident();
         mhx_sketcher_destroy(sk);
         clear_error();
         return stream_fastq_reference(paths, n_paths, k, s, m, hashes, counts, kmers, records, fname, fcomment, handled, true);
@@ -703,7 +797,6 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         counts.resize(n);
         *handled = !rc;
     }
-    hipFree(d_slot);
     free_resident();
     if (sk) mhx_sketcher_destroy(sk);
     return rc;

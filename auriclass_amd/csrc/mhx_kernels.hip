@@ -1239,7 +1239,7 @@ size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, s
     *off_q = o; o += up((size_t)nq * (kDistRanges + 1) * 4);
     *off_r = o; o += up((size_t)nr * (kDistRanges + 1) * 4);
     *off_c = o; o += up((size_t)kDistRanges * nq * 4 * ((nr + 3) / 4));
-    *off_p = o; o += 256;
+    *off_p = o; // behind it: two words per (query batch, reference slice) block, sized by the caller
     return o;
 }
 

@@ -1,0 +1,206 @@
+// mhx_merge.hip -- the sharded path's merge where the data is (north_star: "RCCL all-gather of per-shard
+// partial bottom-s heaps over xGMI before the final merge").  After the all-gather every rank holds all ranks' slabs in
+// HBM: `nranks` unsorted lists of (hash, count), every hash <= its shard's threshold, ~1.1 s entries each without a
+// multiplicity filter and 10-14 s with one (every singleton below the threshold travels: counts must stay summable).
+// The union's sketch = the s smallest hashes <= T_min whose counts, summed over the ranks, reach m.
+//
+// Hash values are uniform, so cutting [0, T_min] into equal value bins cuts the union into equal work:
+//   merge_scatter_kernel  every workgroup takes a chunk of one slab, counts its entries per bin in LDS, reserves room
+//                         in each bin's region with ONE global atomic per (workgroup, bin) and writes the entries there
+//                         (a global atomic per entry would serialise on the memory-side atomic units: ~2.7 G/s)
+//   merge_bin_kernel      one workgroup per bin: the bin's ~1500 entries go through an LDS hash table (64-bit CAS on the
+//                         key, atomic add on the count), the entries with count >= m are ranked among themselves and
+//                         written back, in order, to the head of the bin's region
+//   merge_compact_kernel  prefix over the bins' counts -> the qualifying entries, globally ascending, into the
+//                         pinned result block of the sketcher, header last
+// No pass over the 200 MB candidate table, no atomics on it, nothing sorted on the host.  A bin region or table that
+// overflows (non-uniform input) raises a flag and the caller falls back to the table path (slab_insert_kernel).
+#include "mhx_device.h"
+
+namespace mhx {
+
+constexpr uint32_t kMergeChunk = 65536;  // slab entries per workgroup of the scatter pass
+constexpr uint32_t kMergeMaxQual = 1024; // qualifying entries a bin can rank in LDS
+
+__device__ __forceinline__ bool merge_entry(const MergeArgs &a, uint32_t r, uint64_t i, uint64_t &h, uint32_t &c)
+{
+    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
+    h = hashes[i];
+    if (h > a.t_min || h == kEmptyKey) return false;
+    c = reinterpret_cast<const uint32_t *>(hashes + a.cap)[i];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void merge_scatter_kernel(const MergeArgs a)
+{
+    extern __shared__ uint32_t smem[]; // [nbins] counts, then local cursors | [nbins] bases
+    uint32_t *cnt = smem, *base = smem + a.nbins;
+    const uint32_t r = blockIdx.y;
+    const uint64_t n = a.n[r];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kMergeChunk;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + kMergeChunk < n ? i0 + kMergeChunk : n;
+    for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint64_t h;
+        uint32_t c;
+        if (merge_entry(a, r, i, h, c)) atomicAdd(&cnt[(uint32_t)(h >> a.shift)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) {
+        const uint32_t c = cnt[b];
+        base[b] = c ? atomicAdd(&a.cursor[b], c) : 0u;
+        cnt[b] = 0;
+    }
+    __syncthreads();
+    bool over = false;
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint64_t h;
+        uint32_t c;
+        if (!merge_entry(a, r, i, h, c)) continue;
+        const uint32_t b = (uint32_t)(h >> a.shift);
+        const uint32_t pos = base[b] + atomicAdd(&cnt[b], 1u);
+        if (pos < a.region) {
+            a.sc_keys[(uint64_t)b * a.region + pos] = h;
+            a.sc_cnts[(uint64_t)b * a.region + pos] = c;
+        } else {
+            over = true;
+        }
+    }
+    if (over) atomicOr(a.flags, 1u);
+}
+
+__global__ __launch_bounds__(256) void merge_bin_kernel(const MergeArgs a)
+{
+    extern __shared__ unsigned long long lds[]; // [slots] keys | [slots] u32 counts | [kMergeMaxQual] keys | [kMergeMaxQual] u32 counts
+    unsigned long long *keys = lds;
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(keys + a.table_slots);
+    unsigned long long *qk = reinterpret_cast<unsigned long long *>(cnts + a.table_slots);
+    uint32_t *qc = reinterpret_cast<uint32_t *>(qk + kMergeMaxQual);
+    __shared__ uint32_t nq;
+    const uint32_t b = blockIdx.x, mask = a.table_slots - 1;
+    const uint32_t filled = a.cursor[b];
+    const uint32_t n = filled < a.region ? filled : a.region;
+    for (uint32_t i = threadIdx.x; i < a.table_slots; i += blockDim.x) { keys[i] = kEmptyKey; cnts[i] = 0; }
+    if (threadIdx.x == 0) nq = 0;
+    __syncthreads();
+    if (n > (a.table_slots * 3u) / 4u) { // cannot happen with region <= 3/4 of the table; kept as a guard
+        if (threadIdx.x == 0) { atomicOr(a.flags, 2u); a.qn[b] = 0; a.cursor[b] = 0; }
+        return;
+    }
+    const uint64_t *rk = a.sc_keys + (uint64_t)b * a.region;
+    const uint32_t *rc = a.sc_cnts + (uint64_t)b * a.region;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t h = rk[i];
+        const uint32_t c = rc[i];
+        // the bits below the bin index tell the entries of one bin apart
+        uint32_t sl = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+        for (;;) {
+            unsigned long long cur = keys[sl];
+            if (cur == kEmptyKey) cur = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)h);
+            if (cur == kEmptyKey || cur == h) { atomicAdd(&cnts[sl], c); break; }
+            sl = (sl + 1) & mask;
+        }
+    }
+    __syncthreads();
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < a.table_slots; i += blockDim.x) {
+        if (keys[i] != kEmptyKey && cnts[i] >= a.min_mult) {
+            const uint32_t p = atomicAdd(&nq, 1u);
+            if (p < kMergeMaxQual) { qk[p] = keys[i]; qc[p] = cnts[i]; }
+            else over = true;
+        }
+    }
+    if (over) atomicOr(a.flags, 4u);
+    __syncthreads();
+    const uint32_t q = nq < kMergeMaxQual ? nq : kMergeMaxQual;
+    // in order, back to the head of the bin's own region (its inputs are all in LDS by now)
+    uint64_t *ok = a.sc_keys + (uint64_t)b * a.region;
+    uint32_t *oc = a.sc_cnts + (uint64_t)b * a.region;
+    for (uint32_t t = threadIdx.x; t < q; t += blockDim.x) {
+        const unsigned long long mine = qk[t];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < q; ++j) rank += qk[j] < mine ? 1u : 0u; // the keys of a table are distinct
+        if (rank < a.region) { ok[rank] = mine; oc[rank] = qc[t]; }
+    }
+    if (threadIdx.x == 0) {
+        a.qn[b] = q < a.region ? q : a.region;
+        a.cursor[b] = 0; // zero again for the next merge
+    }
+}
+
+// out: the sketcher's pinned result block [n, T, flags, 0 | hashes[out_cap] | counts[out_cap]] (the layout finish() reads)
+__global__ __launch_bounds__(256) void merge_compact_kernel(const MergeArgs a, uint64_t *out, uint32_t out_cap)
+{
+    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t block_base, grand_total;
+    // every workgroup owns 256 bins and sums the counts of the bins in front of its own
+    const uint32_t first = blockIdx.x * 256;
+    uint32_t before = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < a.nbins; b += 256) { // (nbins <= 16384: at most 64 per thread)
+        const uint32_t v = a.qn[b];
+        all += v;
+        if (b < first) before += v;
+    }
+    // workgroup reduction of (before, all)
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+    __shared__ uint32_t red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        grand_total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    __syncthreads();
+    const uint32_t b = first + threadIdx.x;
+    const uint32_t mine = b < a.nbins ? a.qn[b] : 0u;
+    // exclusive scan of `mine` over the workgroup
+    uint32_t v = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) wave_sums[wave] = v;
+    __syncthreads();
+    uint32_t off = block_base + v - mine;
+    for (int w = 0; w < wave; ++w) off += wave_sums[w];
+    uint32_t *oc = reinterpret_cast<uint32_t *>(out + 4 + out_cap);
+    for (uint32_t j = 0; j < mine; ++j) {
+        if (off + j >= out_cap) break;
+        out[4 + off + j] = a.sc_keys[(uint64_t)b * a.region + j];
+        oc[off + j] = a.sc_cnts[(uint64_t)b * a.region + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = grand_total;
+        out[1] = a.t_min;
+        out[2] = (uint64_t)*a.flags;
+        out[3] = 0;
+        *a.flags = 0;
+    }
+}
+
+hipError_t launch_merge_bins(const MergeArgs &a, uint64_t max_n, uint64_t *out, uint32_t out_cap, hipStream_t st)
+{
+    if (a.nbins < 256 || a.nbins > kMergeMaxBins || (a.nbins & (a.nbins - 1)) || a.table_slots < 256 || a.table_slots > kMergeMaxSlots ||
+        (a.table_slots & (a.table_slots - 1)))
+        return hipErrorInvalidValue;
+    const unsigned chunks = (unsigned)((max_n + kMergeChunk - 1) / kMergeChunk);
+    const size_t scatter_lds = 2 * (size_t)a.nbins * sizeof(uint32_t);
+    const size_t bin_lds = (size_t)a.table_slots * 12 + (size_t)kMergeMaxQual * 12;
+    static bool attr_set = false; // dynamic LDS beyond 64 KB has to be asked for once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(merge_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMergeMaxBins * 4);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(merge_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeMaxSlots * 12 + kMergeMaxQual * 12);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (chunks) hipLaunchKernelGGL(merge_scatter_kernel, dim3(chunks, a.nranks), dim3(256), scatter_lds, st, a);
+    hipLaunchKernelGGL(merge_bin_kernel, dim3(a.nbins), dim3(256), bin_lds, st, a);
+    hipLaunchKernelGGL(merge_compact_kernel, dim3(a.nbins / 256), dim3(256), 0, st, a, out, out_cap);
+    return hipGetLastError();
+}
+
+} // namespace mhx

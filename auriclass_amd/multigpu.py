@@ -142,6 +142,7 @@ def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.
 
     world, rank = dist.get_world_size(), dist.get_rank()
     on_device = device.type == "cuda"
+    sk.sync()   # the shard's own sketch kernels (export_begin would wait for them anyway): not part of the exchange's time
     t0 = time.perf_counter()
     hdr = sk.export_begin()
     t1 = time.perf_counter()

@@ -37,7 +37,7 @@ def _seqs(fq_bytes):
 def _exchange(sk, form, k, s, m):
     """`device`: sizes first, data-sized slabs, merge on the GPU (gloo only carries the bytes); `host`: the
     callback form with the host merge (what the CPU tests of the decision logic run)."""
-    if form == "device":
+    if form.startswith("device"):
         return multigpu.exchange_and_merge_device(sk, torch.device("cpu"))
     return multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
 
@@ -46,6 +46,8 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rat
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if form == "device-table":   # the fallback of the binned merge: the other ranks' entries go into this rank's candidate table
+        os.environ["MHX_MERGE_TABLE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from auriclass_amd import engine
 
@@ -62,7 +64,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rat
     got_h, got_c = _exchange(sk, form, k, s, m)
     np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
-    if form == "device":
+    if form.startswith("device"):
         np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array(multigpu.last_exchange["entries_per_rank"]))
         # the table now holds the union: pushing without a reset must be refused, after a reset the sketcher is as new
         with pytest.raises(engine.EngineError):
@@ -75,7 +77,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rat
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("form", ["device", "host"])
+@pytest.mark.parametrize("form", ["device", "device-table", "host"])
 @pytest.mark.parametrize("world,k,s,m", [(2, 21, 1000, 1), (2, 21, 1000, 3), (3, 27, 5000, 2), (3, 16, 3000, 2)])
 def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, s, m, form):
     from oracle import mash_oracle as mo

@@ -36,10 +36,29 @@ with gzip.open(pg, "wb", compresslevel=1) as fh:
 pg2 = os.path.join(d, "r2.fq.gz")
 with gzip.open(pg2, "wb", compresslevel=1) as fh:
     fh.write(host[3_000_000 * rb: 6_000_000 * rb].tobytes())
-for files in ([pg], [pg, pg2]):
-    t0 = time.perf_counter(); engine.sketch_files(files, 27, 50000, os.path.join(d, "o.msh"), reads=True, min_mult=3); t = time.perf_counter() - t0
-    nb = len(files) * 3_000_000 * 150
-    print(f"file-inclusive {len(files)} x 3 M-read .fq.gz (k=27 s=50000 m=3) {1e3*t:8.1f} ms  {nb/t/1e9:7.3f} Gbases/s")
+def gz_cases(label, sets):
+    """every case at the default thread budget and at explicit ones (MHX_INGEST_THREADS is read per call); best of 2"""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    for threads in (None, 16, 32, 64):
+        if threads is None:
+            os.environ.pop("MHX_INGEST_THREADS", None)
+        else:
+            os.environ["MHX_INGEST_THREADS"] = str(threads)
+        for files in sets:
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter(); engine.sketch_files(files, 27, 50000, os.path.join(d, "o.msh"), reads=True, min_mult=3); ts.append(time.perf_counter() - t0)
+            t = min(ts)
+            nb = len(files) * 3_000_000 * 150
+            tl = f"default budget ({usable} usable cores)" if threads is None else f"MHX_INGEST_THREADS={threads}"
+            print(f"file-inclusive {len(files)} x 3 M-read {label} (k=27 s=50000 m=3), {tl}: {1e3*t:8.1f} ms  {nb/t/1e9:7.3f} Gbases/s", flush=True)
+    os.environ.pop("MHX_INGEST_THREADS", None)
+
+
+gz_cases(".fq.gz", ([pg], [pg, pg2]))
 # the same two files as bgzip writes them (independent 64 KiB members)
 import struct, zlib
 def bgzf(data, level=1, block=0xFF00):
@@ -52,8 +71,5 @@ def bgzf(data, level=1, block=0xFF00):
 pb, pb2 = os.path.join(d, "b1.fq.gz"), os.path.join(d, "b2.fq.gz")
 open(pb, "wb").write(bgzf(host[: 3_000_000 * rb].tobytes()))
 open(pb2, "wb").write(bgzf(host[3_000_000 * rb: 6_000_000 * rb].tobytes()))
-for files in ([pb], [pb, pb2]):
-    t0 = time.perf_counter(); engine.sketch_files(files, 27, 50000, os.path.join(d, "o.msh"), reads=True, min_mult=3); t = time.perf_counter() - t0
-    nb = len(files) * 3_000_000 * 150
-    print(f"file-inclusive {len(files)} x 3 M-read BGZF .fq.gz (k=27 s=50000 m=3) {1e3*t:8.1f} ms  {nb/t/1e9:7.3f} Gbases/s")
+gz_cases("BGZF .fq.gz", ([pb], [pb, pb2]))
 import shutil; shutil.rmtree(d)
