@@ -405,13 +405,17 @@ static int settle(mhx_sketcher *sk)
     return MHX_OK;
 }
 
-int sketcher_release_oldest_push(mhx_sketcher *sk, hipStream_t side, uint32_t *word)
+int sketcher_release_push(mhx_sketcher *sk, const void *d_bytes, hipStream_t side, uint32_t *word)
 {
-    if (!sk || sk->unsettled.empty()) return MHX_OK;
+    if (!sk) return MHX_OK;
+    size_t at = sk->unsettled.size();
+    for (size_t i = 0; i < sk->unsettled.size(); ++i)
+        if (sk->unsettled[i].ptr == d_bytes) { at = i; break; }
+    if (at == sk->unsettled.size()) return MHX_OK; // settled already (an earlier repair pass took everything there was)
     HIPCHK(hipMemcpyAsync(word, sk->d_need, sizeof(uint32_t), hipMemcpyDeviceToHost, side));
     HIPCHK(hipStreamSynchronize(side));
     if (*word == 0) {
-        sk->unsettled.erase(sk->unsettled.begin());
+        sk->unsettled.erase(sk->unsettled.begin() + (long)at);
         return MHX_OK;
     }
     int rc = repair_unsettled(sk); // reads every unsettled span again: all of them are still in place
@@ -580,6 +584,11 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
         if (tile < ntiles) cur = plan(tile, launch);
         // tighten T from what has been seen (also after the last launch of a push: the next push starts from it).
         // Sampled passes (big tables) leave the table marked dirty (an exact pass has not seen it) but sampled: see finish().
+        // (Tried in round 3: the passes between two launches on a side stream, beside the next launch.  Exactness survives
+        // -- any earlier T is a valid bound -- but capacity does not: the next launch's first workgroups then run with the
+        // threshold of TWO chunks ago, which for the second launch is "admit everything" and overflows the table, and
+        // with a multiplicity filter the cap in front of the next launch is decided before the pass can report solid
+        // hashes.  What remains safe saves < 1 % of a step; the passes stay in stream order.)
         ta.next_cap = tile < ntiles ? cur.cap : 0;
         HIPCHK(launch_tighten(ta, g.stream));
         if (ta.sample == 1) sk->table_dirty = false;
@@ -1095,6 +1104,9 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
             HIPCHK(hipStreamSynchronize(g.stream));
             const uint64_t *h = sk->h_fin;
             const uint64_t n_q = h[0];
+            static const bool dbg = getenv("MHX_MERGE_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[mhx merge] %u ranks, %llu entries, %u bins (%llu used) of %u entries, table %u: %llu qualify, flags %llu\n", n_ranks,
+                             (unsigned long long)total, nbins, (unsigned long long)bins_used, a.region, a.table_slots, (unsigned long long)n_q, (unsigned long long)h[2]);
             if (h[2] == 0 && n_q <= sk->fin_cap) {
                 const uint64_t maxkey_all = maxkey_others + headers[8 * (size_t)own_rank + 3];
                 const bool extra = t_min == ~0ull && maxkey_all >= sk->m; // the one hash value no table holds

@@ -62,11 +62,12 @@ int require_engine();
 } // namespace mhx
 
 // FASTQ pushes stay "unsettled" (their bytes may be read again by a repair pass) until a synchronisation point.  A caller
-// that recycles its device buffers push by push (the chunked ingest) asks here whether the OLDEST unsettled push, whose
+// that recycles its device buffers push by push (the chunked ingest) asks here whether the push that read `d_bytes`, whose
 // kernels it knows to have completed, can be let go: the "repair due" word is read on `side` (not behind the kernels of
 // later pushes on the engine stream) into the pinned `word`; still zero -> that push needs no repair and is forgotten;
-// set -> everything unsettled is repaired now, while all of it is still intact (full synchronisation).
-int sketcher_release_oldest_push(mhx_sketcher *sk, hipStream_t side, uint32_t *word);
+// set -> everything unsettled is repaired now, while all of it is still intact (full synchronisation).  A push that is
+// not on the list any more (an earlier repair has taken it) needs nothing.
+int sketcher_release_push(mhx_sketcher *sk, const void *d_bytes, hipStream_t side, uint32_t *word);
 
 // sketcher with `table_scale` times the default candidate table and admission budget
 int create_sketcher(int k, uint32_t s, uint32_t min_mult, uint64_t expected_bytes, uint64_t table_scale, mhx_sketcher **out);

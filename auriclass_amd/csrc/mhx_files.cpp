@@ -386,7 +386,6 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
     size_t carry_len = 0;
     uint64_t produced = 0;     // inflated bytes so far (bounds how far back a match may reach)
     bool first = true;
-    uint64_t lines_before = 0; // newlines in everything already emitted
     const bool dbg = getenv("MHX_INGEST_DEBUG") != nullptr;
     double t_alloc = 0, t_inflate = 0, t_cut = 0, t_put = 0;
     auto now = []() { return std::chrono::steady_clock::now(); };
@@ -480,25 +479,32 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
         t_inflate += secs(t0, now());
         t0 = now();
         if (first && n && d[0] != '@') { st->not_fastq4 = true; close_all(); q->producer_done(); return; }
-        // cut after the last newline that completes a record (line count multiple of 4): a vectorised
-        // newline count, then a short walk back over the unfinished last record; the records themselves
-        // are parsed and counted on the device
+        // Cut in front of the last record start that can be VERIFIED inside the chunk: a line that begins with '@', is
+        // followed by a line that begins with neither '@' nor '+', and then by a line that begins with '+' -- the shape
+        // no quality line can imitate (a quality line may begin with '@', but the line after it is a header and begins
+        // with '@' as well).  A few lines are walked back from the end of the chunk; counting all of its newlines (round
+        // 2) cost this thread a third of its time.  Every chunk thus starts at a record start; the records themselves
+        // are parsed, checked for the 4-line layout and counted on the device.
         size_t cut = 0;
-        uint64_t lines = lines_before + count_newlines(d, n), lines_at_cut = lines_before;
-        {
-            uint64_t back = lines & 3;
-            size_t end = n;
-            const uint8_t *p = (const uint8_t *)memrchr(d, '\n', end);
-            while (p && back) { end = (size_t)(p - d); p = (const uint8_t *)memrchr(d, '\n', end); --back; }
-            if (p) { cut = (size_t)(p - d) + 1; lines_at_cut = lines - (lines & 3); }
-        }
-        if (eof) {
-            // the tail must be whole records; a last record may lack its final newline
-            if (cut < n) { const uint64_t tail_lines = lines - lines_at_cut + 1; if (tail_lines != 4) st->not_fastq4 = true; }
+        if (!eof) {
+            size_t ls[3] = {n, n, n}; // starts of the line under test and of the two lines behind it
+            const uint8_t *p = (const uint8_t *)memrchr(d, '\n', n);
+            for (int walked = 0; p && walked < 4096; ++walked) {
+                const uint8_t *prev = p > d ? (const uint8_t *)memrchr(d, '\n', (size_t)(p - d)) : nullptr;
+                ls[2] = ls[1]; ls[1] = ls[0];
+                ls[0] = (size_t)(p - d) + 1;                 // the line that starts behind newline p ...
+                const size_t start = prev ? (size_t)(prev - d) + 1 : 0; // ... and the one that ends with it
+                // test the line [start, p]: its two successors start at ls[0] and ls[1]
+                if (ls[1] < n && d[start] == '@' && d[ls[0]] != '@' && d[ls[0]] != '+' && d[ls[1]] == '+') { cut = start; break; }
+                p = prev;
+            }
+            if (cut == 0) st->not_fastq4 = true; // no record start in sight (a record larger than a chunk, or not 4-line FASTQ): the record parser
+        } else {
+            // the last chunk starts at a record start like every other: its lines must come in fours (a last record may
+            // lack its final newline)
+            const uint64_t lines = count_newlines(d, n) + (n && d[n - 1] != '\n' ? 1 : 0);
+            if (lines & 3) st->not_fastq4 = true;
             cut = n;
-            lines_at_cut = lines + (n && d[n - 1] != '\n' ? 1 : 0);
-        } else if (cut == 0) {
-            st->not_fastq4 = true; // a single record larger than a chunk: leave it to the record parser
         }
         if (st->not_fastq4) { close_all(); q->producer_done(); return; }
         carry_len = n - cut;
@@ -511,8 +517,6 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
         }
         c.size = cut;
         st->bytes += cut;
-        st->lines = lines_at_cut;
-        lines_before = lines_at_cut;
         first = false;
         t_cut += secs(t0, now());
         t0 = now();
@@ -702,7 +706,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     // 2. compressed files: one inflate thread per file (each with its share of decoding threads), 32 MiB record-aligned
     // chunks in pinned buffers; TWO device slots: chunk j is copied on the copy stream while chunk j - 1 is being parsed
     // and hashed on the engine stream.  A slot is overwritten only when the kernels of its previous chunk have completed
-    // (event) AND that chunk is known to need no repair pass (sketcher_release_oldest_push) -- no whole-stream
+    // (event) AND that chunk is known to need no repair pass (sketcher_release_push) -- no whole-stream
     // synchronisation per chunk.
     std::vector<FileIngestState> st(n_paths);
     if (!rc && !fallback && !queued.empty()) {
@@ -732,7 +736,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
             const int slot = (int)(nchunk & 1);
             if (nchunk >= 2) { // the slot's previous tenant (chunk nchunk - 2): kernels through, repair question settled
                 if (!hip_ok(hipEventSynchronize(g.ingest_consumed[slot]), "event wait")) continue;
-                rc = sketcher_release_oldest_push(sk, g.copy_stream, g.ingest_word);
+                rc = sketcher_release_push(sk, g.ingest_slot[slot], g.copy_stream, g.ingest_word);
                 if (rc) { q.abort(); continue; }
             }
             if (!hip_ok(hipMemcpyAsync(g.ingest_slot[slot], c.data(), c.size, hipMemcpyHostToDevice, g.copy_stream), "H2D copy")) continue;

@@ -486,7 +486,9 @@ __global__ __launch_bounds__(256) void table_tighten_kernel(const TableArgs a)
             now = a.next_cap;
             a.stats[kStatBounded] = 1;
         }
-        if (now < T) *a.thresh = now;
+        // (atomic: a pass between two launches of a push runs beside the next launch's cap_threshold_kernel, and T must
+        // never rise -- a hash that is admitted now must have been admitted on every earlier occurrence)
+        if (now < T) atomicMin(reinterpret_cast<unsigned long long *>(a.thresh), (unsigned long long)now);
     }
 }
 
@@ -500,10 +502,7 @@ __global__ void cap_threshold_kernel(uint64_t *thresh, uint64_t cap, uint64_t *s
     if (stats[kStatEstablished]) return;
     const uint64_t occupied = stats[kStatOccupied], solid = stats[kStatSolid];
     if (occupied > 0 && solid * 5 >= occupied) return;
-    if (*thresh > cap) {
-        *thresh = cap;
-        stats[kStatBounded] = 1;
-    }
+    if (atomicMin(reinterpret_cast<unsigned long long *>(thresh), (unsigned long long)cap) > cap) stats[kStatBounded] = 1;
 }
 
 // FASTQ, self-synchronising form: do the line phases the tiles found (HashArgs::phase_rec) form one chain?

@@ -22,16 +22,9 @@ namespace mhx {
 constexpr uint32_t kMergeChunk = 65536;  // slab entries per workgroup of the scatter pass
 constexpr uint32_t kMergeMaxQual = 1024; // qualifying entries a bin can rank in LDS
 
-__device__ __forceinline__ bool merge_entry(const MergeArgs &a, uint32_t r, uint64_t i, uint64_t &h, uint32_t &c)
-{
-    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
-    h = hashes[i];
-    if (h > a.t_min || h == kEmptyKey) return false;
-    c = reinterpret_cast<const uint32_t *>(hashes + a.cap)[i];
-    return true;
-}
+constexpr int kScatterThreads = 1024, kScatterBatch = 4; // loads in flight per thread: the passes are chains of HBM round trips otherwise
 
-__global__ __launch_bounds__(256) void merge_scatter_kernel(const MergeArgs a)
+__global__ __launch_bounds__(kScatterThreads) void merge_scatter_kernel(const MergeArgs a)
 {
     extern __shared__ uint32_t smem[]; // [nbins] counts, then local cursors | [nbins] bases
     uint32_t *cnt = smem, *base = smem + a.nbins;
@@ -40,12 +33,21 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(const MergeArgs a)
     const uint64_t i0 = (uint64_t)blockIdx.x * kMergeChunk;
     if (i0 >= n) return;
     const uint64_t i1 = i0 + kMergeChunk < n ? i0 + kMergeChunk : n;
+    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(hashes + a.cap);
     for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        uint64_t h;
-        uint32_t c;
-        if (merge_entry(a, r, i, h, c)) atomicAdd(&cnt[(uint32_t)(h >> a.shift)], 1u);
+    constexpr uint64_t kStep = (uint64_t)kScatterThreads * kScatterBatch;
+    for (uint64_t j = i0 + threadIdx.x; j < i1; j += kStep) {
+        uint64_t h[kScatterBatch];
+#pragma unroll
+        for (int u = 0; u < kScatterBatch; ++u) {
+            const uint64_t i = j + (uint64_t)u * kScatterThreads;
+            h[u] = i < i1 ? hashes[i] : kEmptyKey;
+        }
+#pragma unroll
+        for (int u = 0; u < kScatterBatch; ++u)
+            if (h[u] <= a.t_min && h[u] != kEmptyKey) atomicAdd(&cnt[(uint32_t)(h[u] >> a.shift)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) {
@@ -55,17 +57,26 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(const MergeArgs a)
     }
     __syncthreads();
     bool over = false;
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        uint64_t h;
-        uint32_t c;
-        if (!merge_entry(a, r, i, h, c)) continue;
-        const uint32_t b = (uint32_t)(h >> a.shift);
-        const uint32_t pos = base[b] + atomicAdd(&cnt[b], 1u);
-        if (pos < a.region) {
-            a.sc_keys[(uint64_t)b * a.region + pos] = h;
-            a.sc_cnts[(uint64_t)b * a.region + pos] = c;
-        } else {
-            over = true;
+    for (uint64_t j = i0 + threadIdx.x; j < i1; j += kStep) {
+        uint64_t h[kScatterBatch];
+        uint32_t c[kScatterBatch];
+#pragma unroll
+        for (int u = 0; u < kScatterBatch; ++u) {
+            const uint64_t i = j + (uint64_t)u * kScatterThreads;
+            h[u] = i < i1 ? hashes[i] : kEmptyKey;
+            c[u] = i < i1 ? counts[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kScatterBatch; ++u) {
+            if (h[u] > a.t_min || h[u] == kEmptyKey) continue;
+            const uint32_t b = (uint32_t)(h[u] >> a.shift);
+            const uint32_t pos = base[b] + atomicAdd(&cnt[b], 1u);
+            if (pos < a.region) {
+                a.sc_keys[(uint64_t)b * a.region + pos] = h[u];
+                a.sc_cnts[(uint64_t)b * a.region + pos] = c[u];
+            } else {
+                over = true;
+            }
         }
     }
     if (over) atomicOr(a.flags, 1u);
@@ -197,7 +208,7 @@ hipError_t launch_merge_bins(const MergeArgs &a, uint64_t max_n, uint64_t *out, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (chunks) hipLaunchKernelGGL(merge_scatter_kernel, dim3(chunks, a.nranks), dim3(256), scatter_lds, st, a);
+    if (chunks) hipLaunchKernelGGL(merge_scatter_kernel, dim3(chunks, a.nranks), dim3(kScatterThreads), scatter_lds, st, a);
     hipLaunchKernelGGL(merge_bin_kernel, dim3(a.nbins), dim3(256), bin_lds, st, a);
     hipLaunchKernelGGL(merge_compact_kernel, dim3(a.nbins / 256), dim3(256), 0, st, a, out, out_cap);
     return hipGetLastError();

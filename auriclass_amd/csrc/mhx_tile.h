@@ -289,13 +289,41 @@ MHX_HD uint64_t times5_plus(uint64_t h, uint32_t c)
     const uint64_t t = (uint64_t)lo * 5u + c;
     return make64((uint32_t)t, ((hi << 2) + hi) + (uint32_t)(t >> 32));
 }
+// x * C mod 2^64 for a constant C.  hipcc's own sequence is v_mad_u64_u32 (lo * C_lo, 64 bits) + 2 x v_mul_lo_u32 (the cross
+// terms) + v_add3_u32: four quarter-rate VALU instructions (4 cycles each per wave64, profiles/r02_valu_class_rates_
+// microbench.txt).  The device form below makes it three plus one full-rate add: the cross sum lands in the ODD half of a
+// register pair whose even half holds zero, and the last v_mad_u64_u32 takes that pair -- (cross << 32) -- as its 64-bit
+// addend.  The compiler cannot be talked into this by itself (it builds {0, cross} with two v_mov per multiply, round 2's
+// experiment), so the four instructions are one asm block on the fixed pair v[70:71]; `zero` is the variable that lives
+// in v70 (threaded through every call of one hash so that it is materialised once per window, not once per multiply).
+// Round-2's attempt wrapped single instructions and drowned in the s_nops hipcc puts around such blocks; a block of four
+// with no hazard inside gets none (checked in the ISA).  MHX_PLAIN_MUL64 restores the compiler's sequence.
+template <uint64_t C> MHX_HD uint64_t mul64c(uint64_t x, uint32_t &zero)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MHX_PLAIN_MUL64)
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint64_t p, carry;
+    uint32_t y;
+    asm("v_mul_lo_u32 v71, %[lo], %[chi]\n\t"
+        "v_mul_lo_u32 %[y], %[hi], %[clo]\n\t"
+        "v_add_u32_e32 v71, v71, %[y]\n\t"
+        "v_mad_u64_u32 %[p], %[c], %[lo], %[clo], v[70:71]"
+        : [p] "=&v"(p), [c] "=&s"(carry), [y] "=&v"(y), "+{v70}"(zero)
+        : [lo] "v"(lo), [hi] "v"(hi), [clo] "s"((uint32_t)C), [chi] "s"((uint32_t)(C >> 32))
+        : "v71");
+    return p;
+#else
+    (void)zero;
+    return opaque64(x * C);
+#endif
+}
 // fmix64 without its last step (k ^= k >> 33 changes only the low word, see Murmur3Tail::finish)
-MHX_HD uint64_t fmix64_head(uint64_t k)
+MHX_HD uint64_t fmix64_head(uint64_t k, uint32_t &zero)
 {
     k = xorshift33(k);
-    k = opaque64(k * 0xff51afd7ed558ccdull);
+    k = mul64c<0xff51afd7ed558ccdull>(k, zero);
     k = xorshift33(k);
-    return opaque64(k * 0xc4ceb9fe1a85ec53ull);
+    return mul64c<0xc4ceb9fe1a85ec53ull>(k, zero);
 }
 // The hash up to its last two steps: h = xorshift33(a) + xorshift33(b).  The high word of h is
 // hi(a) + hi(b) or that plus one, so `h <= T` implies hi(a) + hi(b) + 1 <= hi(T) + 1 (mod 2^32, see
@@ -319,26 +347,28 @@ template <int K> MHX_HD Murmur3Tail murmur3_core(const uint32_t (&w)[8])
     constexpr uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
     constexpr int NBLK = K / 16, TAIL = K & 15;
     uint64_t h1 = 42, h2 = 42;
+    uint32_t zero = 0; // see mul64c
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         uint64_t k1 = make64(w[4 * b], w[4 * b + 1]);
         uint64_t k2 = make64(w[4 * b + 2], w[4 * b + 3]);
-        k1 = rotl64<31>(opaque64(k1 * c1)); k1 *= c2; h1 ^= k1;
+        k1 = rotl64<31>(mul64c<c1>(k1, zero)); k1 = mul64c<c2>(k1, zero); h1 ^= k1;
         h1 = rotl64<27>(h1); h1 += h2; h1 = times5_plus(h1, 0x52dce729u);
-        k2 = rotl64<33>(opaque64(k2 * c2)); k2 *= c1; h2 ^= k2;
+        k2 = rotl64<33>(mul64c<c2>(k2, zero)); k2 = mul64c<c1>(k2, zero); h2 ^= k2;
         h2 = rotl64<31>(h2); h2 += h1; h2 = times5_plus(h2, 0x38495ab5u);
     }
     if (TAIL > 8) {
         uint64_t k2 = make64(w[(4 * NBLK + 2) & 7], w[(4 * NBLK + 3) & 7]);
-        k2 = rotl64<33>(opaque64(k2 * c2)); k2 *= c1; h2 ^= k2;
+        k2 = rotl64<33>(mul64c<c2>(k2, zero)); k2 = mul64c<c1>(k2, zero); h2 ^= k2;
     }
     if (TAIL > 0) {
         uint64_t k1 = make64(w[(4 * NBLK) & 7], w[(4 * NBLK + 1) & 7]);
-        k1 = rotl64<31>(opaque64(k1 * c1)); k1 *= c2; h1 ^= k1;
+        k1 = rotl64<31>(mul64c<c1>(k1, zero)); k1 = mul64c<c2>(k1, zero); h1 ^= k1;
     }
     h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
     h1 += h2; h2 += h1;
-    return Murmur3Tail{fmix64_head(h1), fmix64_head(h2)};
+    const uint64_t a = fmix64_head(h1, zero), b = fmix64_head(h2, zero);
+    return Murmur3Tail{a, b};
 }
 template <int K> MHX_HD uint64_t murmur3_h1(const uint32_t (&w)[8]) { return murmur3_core<K>(w).finish(); }
 

@@ -250,3 +250,88 @@ def fastq_record_cuts(data, world: int) -> List[int]:
         cuts.append(max(cut, cuts[-1]))
     cuts.append(n)
     return cuts
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One sample, several GPUs, at file level: what /root/reference/auriclass/classes.py:576-596 hands to `mash sketch -r`
+# (the FASTQ files of ONE sample) spread over the ranks of the process group.
+def _first_counted_header(path, k: int) -> Tuple[str, str]:
+    """(name, comment) of the first record of `path` whose sequence holds >= k bytes (the record that names mash's
+    reference); the very first record if the first MiB has none.  Reads the head of the file only."""
+    import zlib
+
+    with open(path, "rb") as fh:
+        head = fh.read(1 << 20)
+    if head[:2] == b"\x1f\x8b":
+        head = zlib.decompressobj(31).decompress(head, 1 << 20)
+    lines = head.split(b"\n")
+    pick = None
+    for i in range(0, len(lines) - 1, 4):
+        if not lines[i].startswith(b"@"):
+            break
+        if pick is None:
+            pick = lines[i]
+        if len(lines[i + 1].rstrip(b"\r")) >= k:
+            pick = lines[i]
+            break
+    if pick is None:
+        return "", ""
+    text = pick[1:].rstrip(b"\r").decode("utf-8", "surrogateescape")
+    name, _, comment = text.partition(" ")
+    if "\t" in name:   # kseq splits the name at the first blank of either kind
+        name, _, rest = text.partition("\t")
+        comment = rest
+    return name, comment
+
+
+def sketch_fastq_files(paths, k: int, s: int, min_mult: int, out_msh, device: torch.device) -> Tuple[str, float]:
+    """`mash sketch -r -m M -o OUT -k K -s S paths...` for ONE sample over all ranks of the initialised process group
+    (one process per GPU): every uncompressed file is cut into `world` record-aligned byte ranges and rank r takes
+    range r of each (fastq_record_cuts only looks at the bytes around the cut points); a gzip file can only be read
+    from its start, so file i goes whole to rank i % world (the usual pair of .fq.gz keeps two GPUs busy, and inflating is
+    what bounds such inputs anyway).  Each rank sketches what it took on its GPU, ONE exchange merges the partial results
+    (sharded_sketch), rank 0 writes the .msh -- the same bytes `engine.sketch_files(..., reads=True)` writes on one GPU.
+    Returns (stderr text, estimated genome size) on every rank.  Strict 4-line FASTQ only (what the device parser
+    takes); anything else: use the single-GPU call."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    pieces = []
+    for i, p in enumerate(paths):
+        with open(p, "rb") as fh:
+            magic = fh.read(2)
+        if magic == b"\x1f\x8b":
+            if i % world == rank:
+                with open(p, "rb") as fh:
+                    pieces.append(np.frombuffer(engine.gunzip(fh.read(), threads=8), dtype=np.uint8))
+        else:
+            mm = np.memmap(p, dtype=np.uint8, mode="r")
+            cuts = fastq_record_cuts(mm, world)
+            if cuts[rank + 1] > cuts[rank]:
+                pieces.append(mm[cuts[rank]:cuts[rank + 1]])
+    nbytes = int(sum(len(x) for x in pieces))
+    records = []
+
+    def push(sk):
+        for piece in pieces:
+            sk.push_host(np.ascontiguousarray(piece), engine.FMT_FASTQ4)
+        sk.sync()
+        records.append(sk.record_count())
+
+    hashes, counts = sharded_sketch(push, k, s, min_mult, nbytes, device)
+    total = torch.tensor([records[-1] if records else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    n_records = int(total.item())
+    if n_records == 0 and len(hashes) == 0:
+        raise engine.NoRecordsError(engine.MHX_E_NO_RECORDS, f'ERROR: Did not find fasta records in "{paths[0]}".')
+    set_size = mult = 0.0
+    if len(hashes):
+        set_size = (2.0 ** (64 if k > 16 else 32)) * len(hashes) / float(hashes[-1])
+        mult = float(counts.astype(np.uint64).sum()) / len(hashes)
+    name, comment = _first_counted_header(paths[0], k)
+    text = f"{name} {comment}"
+    if n_records > 1:
+        text = f"[{n_records} seqs] {text} [...]"
+    if rank == 0:
+        engine.msh_write(out_msh, k, s, [str(paths[0])], [text], [int(set_size)], [hashes])
+    dist.barrier()
+    stderr = "Estimated genome size: %g\nEstimated coverage:    %g\nWriting to %s...\n" % (set_size, mult, out_msh)
+    return stderr, set_size

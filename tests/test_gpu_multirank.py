@@ -332,3 +332,49 @@ def test_device_slab_exchange_retries_a_capped_shard(tmp_path):
     want, _ = ref.finish()
     assert np.array_equal(np.load(tmp_path / "h.npy"), want)
     assert int(np.load(tmp_path / "a.npy")[0]) >= 2
+
+
+# ---- one sample over several GPUs at file level (what classes.py:576-596 hands to `mash sketch -r`) ----------------
+def _files_worker(rank, world, port, paths, k, s, m, out_msh, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auriclass_amd import engine
+
+    engine.init(0)
+    text, size = multigpu.sketch_fastq_files(paths, k, s, m, out_msh, torch.device("cpu"))
+    with open(os.path.join(out_dir, f"stderr{rank}.txt"), "w") as fh:
+        fh.write(text)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["plain", "gz_pair"])
+def test_sharded_file_level_sketch_writes_the_single_gpu_msh(tmp_path, kind):
+    """multigpu.sketch_fastq_files over 2 ranks (byte-range shards of plain files, whole files of a .gz pair) writes the
+    bytes engine.sketch_files(..., reads=True) writes on one GPU, and reports the same genome size."""
+    import gzip
+
+    from auriclass_amd import engine
+
+    k, s, m, world = 27, 5000, 3, 2
+    data = _ragged_input()
+    half = data.index(b"\n@r20000\n") + 1
+    if kind == "plain":
+        paths = [str(tmp_path / "a.fq"), str(tmp_path / "b.fq")]
+        (tmp_path / "a.fq").write_bytes(data[:half])
+        (tmp_path / "b.fq").write_bytes(data[half:])
+    else:
+        paths = [str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq.gz")]
+        (tmp_path / "a.fq.gz").write_bytes(gzip.compress(data[:half], 1))
+        (tmp_path / "b.fq.gz").write_bytes(gzip.compress(data[half:], 1))
+    sharded = tmp_path / "sharded.msh"
+    mp.spawn(_files_worker, args=(world, _free_port(), paths, k, s, m, str(sharded), str(tmp_path)), nprocs=world, join=True)
+    engine.init(0)
+    single = tmp_path / "single.msh"
+    text, size = engine.sketch_files(paths, k, s, single, reads=True, min_mult=m)
+    assert sharded.read_bytes() == single.read_bytes()
+    want_lines = [ln for ln in text.splitlines() if ln.startswith("Estimated")]
+    for r in range(world):
+        got = (tmp_path / f"stderr{r}.txt").read_text()
+        assert [ln for ln in got.splitlines() if ln.startswith("Estimated")] == want_lines
