@@ -1107,7 +1107,7 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
             static const bool dbg = getenv("MHX_MERGE_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[mhx merge] %u ranks, %llu entries, %u bins (%llu used) of %u entries, table %u: %llu qualify, flags %llu\n", n_ranks,
                              (unsigned long long)total, nbins, (unsigned long long)bins_used, a.region, a.table_slots, (unsigned long long)n_q, (unsigned long long)h[2]);
-            if (h[2] == 0 && n_q <= sk->fin_cap) {
+            if (h[2] == 0) { // (more qualify than the block holds? the bins are in value order: its first s entries are the sketch)
                 const uint64_t maxkey_all = maxkey_others + headers[8 * (size_t)own_rank + 3];
                 const bool extra = t_min == ~0ull && maxkey_all >= sk->m; // the one hash value no table holds
                 const uint64_t n_src = n_q + (extra ? 1 : 0);
@@ -1115,14 +1115,14 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
                     return fail(MHX_E_CAPACITY, "sharded sketch not exact: %llu of %u entries with multiplicity >= %u below the smallest shard threshold; "
                                 "every rank must sketch its shard again with a larger budget_scale", (unsigned long long)n_src, sk->s, sk->m);
                 const uint32_t nn = n_src < sk->s ? (uint32_t)n_src : sk->s;
-                const uint32_t from_block = nn < n_q ? nn : (uint32_t)n_q;
+                const uint32_t from_block = nn < n_q ? nn : (uint32_t)n_q; // <= s <= fin_cap: all of them are in the block
                 memcpy(hashes, h + 4, (size_t)from_block * sizeof(uint64_t));
                 if (counts) memcpy(counts, reinterpret_cast<const uint32_t *>(h + 4 + sk->fin_cap), (size_t)from_block * sizeof(uint32_t));
                 if (nn > from_block) { hashes[from_block] = ~0ull; if (counts) counts[from_block] = maxkey_all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)maxkey_all; }
                 *n_out = nn;
                 return MHX_OK;
             }
-            // (flags raised or more qualifying entries than the block holds: the table path decides)
+            // (flags raised -- a bin's region or table overflowed on non-uniform data: the table path decides)
         }
     }
     const uint64_t occupied = headers[8 * (size_t)own_rank + 4];

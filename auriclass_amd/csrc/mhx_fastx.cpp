@@ -130,7 +130,7 @@ int ingest_thread_budget()
     long ranks = 1;
     if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1L, atol(e));
     n /= ranks;
-    return (int)std::min(64L, std::max(2L, n));
+    return (int)std::min(32L, std::max(2L, n)); // measured on a 256-core host: 32 decode threads beat 16 and 64 (profiles/r03_c3_inclusive.txt)
 }
 
 static inline bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }

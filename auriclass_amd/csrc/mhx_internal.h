@@ -35,7 +35,7 @@ int msh_read_file(const char *path, SketchSet &s);
 int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);
 // Host threads the ingest may use (inflate, pread): MHX_INGEST_THREADS, else the cores this process may run on
 // (sched_getaffinity, the cgroup's CPU quota if it has one) divided by the ranks of this node (LOCAL_WORLD_SIZE: one
-// process per GPU), at most 64, at least 2.
+// process per GPU), at most 32, at least 2.
 int ingest_thread_budget();
 struct ParsedRecords {
     std::vector<uint8_t> seq;  // bases of counted records, '\n' after each record (MHX_FMT_SEQ)

@@ -290,17 +290,21 @@ MHX_HD uint64_t times5_plus(uint64_t h, uint32_t c)
     return make64((uint32_t)t, ((hi << 2) + hi) + (uint32_t)(t >> 32));
 }
 // x * C mod 2^64 for a constant C.  hipcc's own sequence is v_mad_u64_u32 (lo * C_lo, 64 bits) + 2 x v_mul_lo_u32 (the cross
-// terms) + v_add3_u32: four quarter-rate VALU instructions (4 cycles each per wave64, profiles/r02_valu_class_rates_
-// microbench.txt).  The device form below makes it three plus one full-rate add: the cross sum lands in the ODD half of a
-// register pair whose even half holds zero, and the last v_mad_u64_u32 takes that pair -- (cross << 32) -- as its 64-bit
-// addend.  The compiler cannot be talked into this by itself (it builds {0, cross} with two v_mov per multiply, round 2's
-// experiment), so the four instructions are one asm block on the fixed pair v[70:71]; `zero` is the variable that lives
-// in v70 (threaded through every call of one hash so that it is materialised once per window, not once per multiply).
-// Round-2's attempt wrapped single instructions and drowned in the s_nops hipcc puts around such blocks; a block of four
-// with no hazard inside gets none (checked in the ISA).  MHX_PLAIN_MUL64 restores the compiler's sequence.
+// terms) + v_add3_u32: four quarter-rate VALU instructions (4 cycles each per wave64 in isolation,
+// profiles/r02_valu_class_rates_microbench.txt).  -DMHX_ASM_MUL64 selects an experiment of round 3 instead: three of them
+// plus one full-rate add -- the cross sum lands in the ODD half of a register pair whose even half holds zero, and the
+// last v_mad_u64_u32 takes that pair, (cross << 32), as its 64-bit addend.  The compiler cannot be talked into this by
+// itself (it builds {0, cross} with two v_mov per multiply), so the four instructions are one asm block on the fixed pair
+// v[70:71]; `zero` is the variable that lives in v70, threaded through every call of one hash.  A block of four with no
+// hazard inside gets no s_nop brackets (round 2 wrapped single instructions and drowned in them).  Measured in the
+// kernel (profiles/r03_hash_loop_asm_multiply_ab.txt): k=21 -0.3 %, k=27 +2.0 % -- no gain: 80 v_add3 became 80
+// v_add_u32 per group of 8 windows, but 13 v_mov and 14 s_nop came with the fixed registers, and inside the kernel an
+// instruction costs its ~3.5 issue cycles whatever its class.  The count is what matters, and four
+// instructions per multiply is the floor: the 64-bit addend of v_mad_u64_u32 must be an even-aligned pair, and the value
+// that has to go into its ODD half is produced in an even one.  The compiler's sequence stays the default.
 template <uint64_t C> MHX_HD uint64_t mul64c(uint64_t x, uint32_t &zero)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MHX_PLAIN_MUL64)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MHX_ASM_MUL64)
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     uint64_t p, carry;
     uint32_t y;
