@@ -364,6 +364,7 @@ def main() -> None:
         np.savez(args.dump_sketch, hashes=result[0], counts=result[1])
     sk.close()
     if use_dist:
+        dist.barrier()   # rank 0 may have spent a while in the parity gate: leave together
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()

@@ -21,6 +21,15 @@ python tools/c3_inclusive.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c3_inclusive.
 python tools/c2_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c2_file_level.txt
 python tools/dist_c5.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/${TAG}_dist_c5.json
 python tools/sample_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sample_end_to_end.txt
-MHX_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --reads 4000000 --no-cpu-baseline 2>&1 | tail -1 > $O/${TAG}_bench_2ranks_gloo_rehearsal.json
+python tools/make_traffic.py $O/${TAG}_pmc_summary.json $O/${TAG}_kernel_stats_trace.csv $O/${TAG}_bench_line_under_trace.json $O/traffic.json $TAG > /dev/null
+# sustained clocks: the same step 1200 times (> 5 s of kernels back to back)
+python bench.py --no-cpu-baseline --steps 1200 --warmup 5 2>&1 | tail -1 > $O/${TAG}_bench_line_sustained_1200_steps.json
+# the sharded path: merge cost on one rank with the GPU to itself, then 5 ranks sharing the GPU (gloo) through bench.py
+python tools/merge_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sharded_merge_time.txt
+tools/rehearse_ranks.sh $O 5 > $O/rehearse.log 2>&1
+for f in $O/r03_rehearsal_*.json; do tail -1 $f > $f.tmp && mv $f.tmp $f; done
+tools/profile_dist.sh > $O/profile_dist.log 2>&1
+cp gpurun_out/prof_dist/summary_pmc_summary.json $O/${TAG}_dist_c5_pmc_summary.json
+cp gpurun_out/prof_dist/summary_kernel_stats_c5trace.csv $O/${TAG}_dist_c5_kernel_stats.csv
 ls -la $O
 echo round profiles done
