@@ -1157,6 +1157,106 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
     }
 }
 
+// The same pass with ONE QUERY PER LANE (round 3; used when a chunk holds enough queries to fill the lanes): lane t walks
+// the slice of query q0 + t in this range element by element -- load, table probe, spread of the reference mask into
+// byte counters -- so that nothing has to be reduced across lanes: the kernel above spends 60 of its ~170 VALU
+// instructions per (query, range) slice on the wave-wide tally of a slice that fills 49 of 64 lanes once, this one spends
+// ~40 per ELEMENT ROUND of 64 slices, i.e. a quarter of the instructions per element.  Each lane reads its own row
+// (16-byte loads where the pair is aligned: a 64-byte line serves four loads of the same lane out of L1/L2), the rows
+// of a workgroup's 256 queries are 256 concurrent streams.
+__global__ __launch_bounds__(256) void dist_range_lane_kernel(const DistArgs a, DistWork w)
+{
+    __shared__ unsigned long long keys[kDistTableSlots];
+    __shared__ uint32_t masks[kDistTableSlots];
+    __shared__ uint32_t too_big;
+    const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < kDistTableSlots; i += 256) { keys[i] = kEmptyKey; masks[i] = 0; }
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (uint32_t r = 0; r < a.nr; ++r) tot += w.offs_r[r * per + p + 1] - w.offs_r[r * per + p];
+        too_big = tot > (kDistTableSlots * 3) / 4;
+        if (too_big) atomicOr(&w.params[1], 1u);
+    }
+    __syncthreads();
+    if (too_big) return;
+    auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
+    for (uint32_t r = wave; r < a.nr; r += 4) { // build: wave w inserts references w, w + 4, ...
+        const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
+        for (uint32_t i = b + lane; i < e; i += 64) {
+            const uint64_t v = a.r[(uint64_t)r * a.stride + i];
+            uint32_t sl = slot_of(v);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
+                if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
+                sl = (sl + 1) & (kDistTableSlots - 1);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t q = blockIdx.y * 256 + tid;
+    if (q >= a.nq) return;
+    const uint32_t nwords = (a.nr + 3) / 4;
+    const uint32_t b = w.offs_q[q * per + p], e = w.offs_q[q * per + p + 1];
+    uint32_t *dst = reinterpret_cast<uint32_t *>(w.cpart + ((uint64_t)q * kDistRanges + p) * (4 * nwords));
+    if (e - b > 255u) { // a byte counter could overflow: not a uniform input, the generic kernel takes over
+        atomicOr(&w.params[1], 1u);
+        return;
+    }
+    const uint64_t *row = a.q + (uint64_t)q * a.stride;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto one = [&](uint64_t v) {
+        uint32_t sl = slot_of(v), m = 0;
+        for (;;) {
+            const unsigned long long kx = keys[sl];
+            if (kx == v) { m = masks[sl]; break; }
+            if (kx == kEmptyKey) break;
+            sl = (sl + 1) & (kDistTableSlots - 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) // bits 4j .. 4j+3 of the mask -> the low bit of four bytes
+            if (j < (int)nwords) acc[j] += (((m >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
+    };
+    if ((reinterpret_cast<uintptr_t>(row) & 63) == 0 && (a.stride & 7u) == 0) { // (rows of whole lines: nothing is read beyond a row)
+        // whole 64-byte lines, each fetched ONCE by the one lane that needs it (four 16-byte loads issued together; with
+        // a load per pair of elements a line was fetched up to four times, and 1500 concurrent streams per CU do not fit
+        // in its L1); the elements of the first and last line that lie outside the slice are skipped
+        uint4 nx[4]; // the line after the one being worked on is already on its way
+        const uint32_t first = b & ~7u;
+        if (first < e) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nx[u] = *reinterpret_cast<const uint4 *>(row + first + 2 * u);
+        }
+        for (uint32_t i0 = first; i0 < e; i0 += 8) {
+            uint4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = nx[u];
+            if (i0 + 8 < e) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nx[u] = *reinterpret_cast<const uint4 *>(row + i0 + 8 + 2 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 2 * u;
+                if (i >= b && i < e) one(((uint64_t)x[u].y << 32) | x[u].x);
+                if (i + 1 >= b && i + 1 < e) one(((uint64_t)x[u].w << 32) | x[u].z);
+            }
+        }
+    } else {
+        uint32_t i = b;
+        if (i < e && ((reinterpret_cast<uintptr_t>(row + i) & 15) != 0)) { one(row[i]); ++i; }
+        for (; i + 2 <= e; i += 2) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(row + i);
+            one(((uint64_t)x.y << 32) | x.x);
+            one(((uint64_t)x.w << 32) | x.z);
+        }
+        if (i < e) one(row[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < (int)nwords) dst[j] = acc[j];
+}
+
 // 16 pairs per workgroup; thread (seg, pair) first sums its 64 ranges, then the 16 threads of
 // segment 0 locate the cut segment, walk it range by range and finish the cut range with the
 // sequential two-pointer rule.
@@ -1246,7 +1346,9 @@ hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t 
 {
     hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
     hipLaunchKernelGGL(dist_split_kernel, dim3(a.nq + a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w);
-    hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
+    static const bool no_lane = getenv("MHX_DIST_NO_LANE") != nullptr;
+    if (a.nq >= 128 && !no_lane) hipLaunchKernelGGL(dist_range_lane_kernel, dim3(kDistRanges, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
+    else hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
     const uint32_t pairs = a.nq * a.nr;
     hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 15) / 16), dim3(256), 0, st, a, w);
     return hipGetLastError();
