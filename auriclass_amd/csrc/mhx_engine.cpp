@@ -77,7 +77,8 @@ extern "C" void mhx_shutdown(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     if (g.fasta.sk) mhx_sketcher_destroy(g.fasta.sk);
-    hipFree(g.fasta.d_raw); hipFree(g.fasta.d_out); hipFree(g.fasta.d_ws); hipFree(g.fasta.d_seps);
+    for (int i = 0; i < 2; ++i) { hipFree(g.fasta.d_raw[i]); if (g.fasta.raw_ready[i]) hipEventDestroy(g.fasta.raw_ready[i]); }
+    hipFree(g.fasta.d_out); hipFree(g.fasta.d_ws); hipFree(g.fasta.d_seps);
     if (g.fasta.h_words) hipHostFree(g.fasta.h_words);
     hipFree(g.dist_ws);
     hipFree(g.dist_in);

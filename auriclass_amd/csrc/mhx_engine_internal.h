@@ -20,7 +20,9 @@ namespace mhx {
 // seen, one sketcher per (k, s) that is reset between files (no hipMalloc / hipFree and no 200 MB table set-up per file)
 constexpr uint32_t kFastaSepsInline = 4096; // record positions that come back with the first synchronisation
 struct FastaCtx {
-    uint8_t *d_raw = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    uint8_t *d_raw[2] = {nullptr, nullptr}; // file i uses d_raw[i & 1]: file i + 1 is copied in while file i is parsed and sketched
+    hipEvent_t raw_ready[2] = {nullptr, nullptr};
+    uint8_t *d_out = nullptr, *d_ws = nullptr;
     uint64_t *d_seps = nullptr;
     size_t raw_cap = 0, ws_cap = 0;
     uint32_t seps_cap = 0;

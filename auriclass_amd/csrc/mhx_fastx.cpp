@@ -124,7 +124,9 @@ int ingest_thread_budget()
     if (n <= 0) n = (long)std::thread::hardware_concurrency();
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2 quota: "max 100000" or "<quota> <period>"
         long long quota = 0, period = 0;
-        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<long>(n, (long)((quota + period - 1) / period));
+        // (twice the quota: the decoding threads spend a good part of their time waiting for each other's windows --
+        // on the GPU box, 16 CPUs of quota, 32 threads beat 16 by 14 %)
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<long>(n, 2 * (long)((quota + period - 1) / period));
         fclose(f);
     }
     long ranks = 1;

@@ -847,24 +847,27 @@ bool nth_header(const uint8_t *b, size_t n, uint64_t idx, std::string &name, std
 
 // One FASTA file, bytes in host memory (a pinned staging slot or a vector) -> its reference sketch.  Device buffers and the
 // sketcher live in g.fasta between files and calls; two stream synchronisations per file (record layout, sketch).
-static int sketch_fasta_on_device(const uint8_t *raw, uint64_t n, int k, uint32_t s, std::vector<uint64_t> &hashes, FastaInfo &info)
+// device buffers of the FASTA path for files of up to n bytes (both raw buffers, the stream, the workspace), the pinned
+// word block, the record positions, the two "raw bytes are in place" events
+static int ensure_fasta_buffers(uint64_t n)
 {
-    if (n == 0 || raw[0] != '>' || n > 0x7FFFFFFF00ull) return kFastaNotForDevice;
     FastaCtx &c = g.fasta;
     size_t os, oi, oo, of;
     const size_t ws_bytes = fasta_workspace_bytes(n, &os, &oi, &oo, &of);
-    const uint64_t ntiles = (n + kFastaTile - 1) / kFastaTile;
     if (!c.h_words) HIPCHK(hipHostMalloc((void **)&c.h_words, (2 + (size_t)kFastaSepsInline) * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i)
+        if (!c.raw_ready[i]) HIPCHK(hipEventCreateWithFlags(&c.raw_ready[i], hipEventDisableTiming));
     if (c.raw_cap < n + 64 || c.ws_cap < ws_bytes) { // grow with room: the next assembly is about as large as this one
         HIPCHK(hipStreamSynchronize(g.stream));
-        hipFree(c.d_raw); hipFree(c.d_out); hipFree(c.d_ws);
-        c.d_raw = c.d_out = c.d_ws = nullptr;
+        if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
+        hipFree(c.d_raw[0]); hipFree(c.d_raw[1]); hipFree(c.d_out); hipFree(c.d_ws);
+        c.d_raw[0] = c.d_raw[1] = c.d_out = c.d_ws = nullptr;
         c.raw_cap = c.ws_cap = 0;
         const size_t want = (size_t)(n + n / 4 + (1u << 20));
         size_t os2, oi2, oo2, of2;
         const size_t ws_want = fasta_workspace_bytes(want, &os2, &oi2, &oo2, &of2);
-        if (hipMalloc((void **)&c.d_raw, want + 64) != hipSuccess || hipMalloc((void **)&c.d_out, want + 64) != hipSuccess ||
-            hipMalloc((void **)&c.d_ws, ws_want) != hipSuccess)
+        if (hipMalloc((void **)&c.d_raw[0], want + 64) != hipSuccess || hipMalloc((void **)&c.d_raw[1], want + 64) != hipSuccess ||
+            hipMalloc((void **)&c.d_out, want + 64) != hipSuccess || hipMalloc((void **)&c.d_ws, ws_want) != hipSuccess)
             return fail(MHX_E_HIP, "hipMalloc failed for the FASTA buffers (%llu bytes)", (unsigned long long)n);
         c.raw_cap = want + 64;
         c.ws_cap = ws_want;
@@ -873,11 +876,29 @@ static int sketch_fasta_on_device(const uint8_t *raw, uint64_t n, int k, uint32_
         c.seps_cap = 1u << 16;
         if (hipMalloc((void **)&c.d_seps, (size_t)c.seps_cap * 8) != hipSuccess) { c.seps_cap = 0; return fail(MHX_E_HIP, "hipMalloc failed for the FASTA record positions"); }
     }
-    HIPCHK(hipMemcpyAsync(c.d_raw, raw, n, hipMemcpyHostToDevice, g.stream));
+    return MHX_OK;
+}
+
+// One FASTA file, bytes in host memory (a pinned staging slot or a vector) -> its reference sketch.  Device buffers and the
+// sketcher live in g.fasta between files and calls; two stream synchronisations per file (record layout, sketch).
+// which: the raw buffer of this file (d_raw[which]); on_device: the loader has already copied the bytes there on the copy
+// stream (raw_ready[which] says when)
+static int sketch_fasta_on_device(const uint8_t *raw, uint64_t n, int which, bool on_device, int k, uint32_t s, std::vector<uint64_t> &hashes, FastaInfo &info)
+{
+    if (n == 0 || raw[0] != '>' || n > 0x7FFFFFFF00ull) return kFastaNotForDevice;
+    FastaCtx &c = g.fasta;
+    int rc0 = ensure_fasta_buffers(n);
+    if (rc0) return rc0;
+    size_t os, oi, oo, of;
+    fasta_workspace_bytes(n, &os, &oi, &oo, &of);
+    const uint64_t ntiles = (n + kFastaTile - 1) / kFastaTile;
+    uint8_t *d_raw = c.d_raw[which & 1];
+    if (on_device) HIPCHK(hipStreamWaitEvent(g.stream, c.raw_ready[which & 1], 0));
+    else HIPCHK(hipMemcpyAsync(d_raw, raw, n, hipMemcpyHostToDevice, g.stream));
     uint64_t total = 0;
     uint32_t nsep = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(launch_fasta_compact(c.d_raw, n, c.d_ws, c.d_out, c.d_seps, c.seps_cap, g.stream));
+        HIPCHK(launch_fasta_compact(d_raw, n, c.d_ws, c.d_out, c.d_seps, c.seps_cap, g.stream));
         HIPCHK(hipMemcpyAsync(&c.h_words[0], c.d_ws + oo + 8 * ntiles, 8, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipMemcpyAsync(&c.h_words[1], c.d_ws + of, 8, hipMemcpyDeviceToHost, g.stream));
         // the record positions of an assembly (tens to hundreds of contigs) ride along with the same synchronisation
@@ -953,11 +974,14 @@ struct FastaInput {
     const uint8_t *data = nullptr;
     uint64_t n = 0;
     int slot = -1;
+    bool on_device = false; // the bytes are already on their way into the file's raw buffer (raw_ready event)
     int rc = MHX_OK;
     std::string error; // (mhx_last_error is thread-local: the message travels with the input)
 };
 
-static void load_fasta_input(const char *path, int slot, bool pinned_ok, FastaInput *in)
+// d_dst != nullptr: the file's raw device buffer is free and large enough -- every reader thread sends what it has read
+// on the copy stream right away (MiB by MiB), so the copy runs beside the reading instead of behind it
+static void load_fasta_input(const char *path, int slot, bool pinned_ok, FastaInput *in, uint8_t *d_dst, size_t d_cap, hipEvent_t ready)
 {
     (void)hipSetDevice(g.device);
     struct stat sb;
@@ -966,10 +990,37 @@ static void load_fasta_input(const char *path, int slot, bool pinned_ok, FastaIn
         if (fd >= 0) {
             bool ok = hipEventSynchronize(g.pinned_free[slot]) == hipSuccess;
             const size_t len = (size_t)sb.st_size;
+            const bool stream = d_dst && len + 64 <= d_cap;
             const int nthreads = len >= (4u << 20) ? std::min(8, ingest_thread_budget()) : 1;
-            ok = ok && parallel_pread(fd, g.pinned[slot], 0, len, nthreads);
+            uint8_t *dst = g.pinned[slot];
+            std::vector<std::thread> th;
+            std::vector<int> good((size_t)nthreads, 1);
+            const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
+            for (int t = 0; ok && t < nthreads; ++t) {
+                const size_t b = (size_t)t * per;
+                if (b >= len) break;
+                const size_t e = std::min(len, b + per);
+                th.emplace_back([=, &good]() {
+                    (void)hipSetDevice(g.device);
+                    size_t done = b, sent = b;
+                    while (done < e) {
+                        const ssize_t got = pread(fd, dst + done, std::min<size_t>(e - done, 1u << 20), (off_t)done);
+                        if (got <= 0) { good[(size_t)t] = 0; return; }
+                        done += (size_t)got;
+                        if (stream && (done - sent >= (1u << 20) || done == e)) {
+                            if (hipMemcpyAsync(d_dst + sent, dst + sent, done - sent, hipMemcpyHostToDevice, g.copy_stream) != hipSuccess) { good[(size_t)t] = 0; return; }
+                            sent = done;
+                        }
+                    }
+                });
+            }
+            for (auto &t : th) t.join();
+            for (int v : good) ok = ok && v;
             close(fd);
-            if (ok) { in->data = g.pinned[slot]; in->n = len; in->slot = slot; return; }
+            if (ok && stream) ok = hipEventRecord(ready, g.copy_stream) == hipSuccess;
+            if (ok) { in->data = dst; in->n = len; in->slot = slot; in->on_device = stream; return; }
+            if (stream) (void)hipStreamSynchronize(g.copy_stream); // nothing of a failed load may still be in flight
+            (void)hipGetLastError();
         }
     }
     in->rc = read_all_maybe_gz(path, in->owned);
@@ -1075,19 +1126,30 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
         const bool pinned_ok = !getenv("MHX_HOST_FASTA") && ensure_pinned_ring() == MHX_OK;
         if (!pinned_ok) { clear_error(); (void)hipGetLastError(); }
         std::vector<FastaInput> inputs(n_paths);
+        // the device buffers are sized for the largest uncompressed input up front, so that a loader can copy file i + 1
+        // into its raw buffer while file i is still on the GPU
+        uint64_t largest = 0;
+        for (int i = 0; i < n_paths; ++i) {
+            struct stat sb;
+            if (stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode) && !is_gzip_file(paths[i])) largest = std::max<uint64_t>(largest, (uint64_t)sb.st_size);
+        }
+        bool stream_ok = pinned_ok && largest > 0 && largest + 64 <= kBulkBlock && ensure_fasta_buffers(largest) == MHX_OK;
+        if (!stream_ok) clear_error();
+        auto raw_of = [&](int i) { return stream_ok ? g.fasta.d_raw[i & 1] : (uint8_t *)nullptr; };
         std::thread loader;
         struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{loader};
-        load_fasta_input(paths[0], 0, pinned_ok, &inputs[0]);
+        load_fasta_input(paths[0], 0, pinned_ok, &inputs[0], raw_of(0), g.fasta.raw_cap, g.fasta.raw_ready[0]);
         for (int i = 0; i < n_paths; ++i) {
             if (loader.joinable()) loader.join();
-            if (i + 1 < n_paths) loader = std::thread(load_fasta_input, paths[i + 1], (i + 1) % Engine::kPinnedSlots, pinned_ok, &inputs[i + 1]);
+            if (i + 1 < n_paths) loader = std::thread(load_fasta_input, paths[i + 1], (i + 1) % Engine::kPinnedSlots, pinned_ok, &inputs[i + 1],
+                                                      raw_of(i + 1), g.fasta.raw_cap, g.fasta.raw_ready[(i + 1) & 1]);
             FastaInput &in = inputs[i];
             err += std::string("Sketching ") + paths[i] + "...\n";
             if (in.rc) return fail(in.rc, "%s", in.error.c_str());
             if (!getenv("MHX_HOST_FASTA")) { // plain FASTA: parsed on the device
                 RefSketch ref;
                 FastaInfo info;
-                rc = sketch_fasta_on_device(in.data, in.n, k, s, ref.hashes, info);
+                rc = sketch_fasta_on_device(in.data, in.n, i, in.on_device, k, s, ref.hashes, info);
                 if (rc < 0) return rc;
                 if (rc == MHX_OK) {
                     if (info.records == 0) return no_records(paths[i]);

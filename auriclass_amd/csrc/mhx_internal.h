@@ -34,7 +34,7 @@ int msh_read_file(const char *path, SketchSet &s);
 // ---- FASTA/FASTQ ingest (mhx_fastx.cpp) -------------------------------------------------
 int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);
 // Host threads the ingest may use (inflate, pread): MHX_INGEST_THREADS, else the cores this process may run on
-// (sched_getaffinity, the cgroup's CPU quota if it has one) divided by the ranks of this node (LOCAL_WORLD_SIZE: one
+// (sched_getaffinity, twice the cgroup's CPU quota if it has one) divided by the ranks of this node (LOCAL_WORLD_SIZE: one
 // process per GPU), at most 32, at least 2.
 int ingest_thread_budget();
 struct ParsedRecords {

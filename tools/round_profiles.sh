@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/ quotes for one round, in one gpurun call:  tools/round_profiles.sh r02
+# Everything profiles/ quotes for one round, in two gpurun calls:  tools/round_profiles.sh r03 ; tools/round_profiles2.sh r03
 # (bench lines, kernel trace + PMC passes of the headline command, inclusive timings, C2, C5, one AuriClass-sized sample)
 set -o pipefail
 TAG=${1:-rXX}
@@ -21,15 +21,5 @@ python tools/c3_inclusive.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c3_inclusive.
 python tools/c2_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c2_file_level.txt
 python tools/dist_c5.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/${TAG}_dist_c5.json
 python tools/sample_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sample_end_to_end.txt
-python tools/make_traffic.py $O/${TAG}_pmc_summary.json $O/${TAG}_kernel_stats_trace.csv $O/${TAG}_bench_line_under_trace.json $O/traffic.json $TAG > /dev/null
-# sustained clocks: the same step 1200 times (> 5 s of kernels back to back)
-python bench.py --no-cpu-baseline --steps 1200 --warmup 5 2>&1 | tail -1 > $O/${TAG}_bench_line_sustained_1200_steps.json
-# the sharded path: merge cost on one rank with the GPU to itself, then 5 ranks sharing the GPU (gloo) through bench.py
-python tools/merge_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sharded_merge_time.txt
-tools/rehearse_ranks.sh $O 5 > $O/rehearse.log 2>&1
-for f in $O/r03_rehearsal_*.json; do tail -1 $f > $f.tmp && mv $f.tmp $f; done
-tools/profile_dist.sh > $O/profile_dist.log 2>&1
-cp gpurun_out/prof_dist/summary_pmc_summary.json $O/${TAG}_dist_c5_pmc_summary.json
-cp gpurun_out/prof_dist/summary_kernel_stats_c5trace.csv $O/${TAG}_dist_c5_kernel_stats.csv
 ls -la $O
 echo round profiles done
