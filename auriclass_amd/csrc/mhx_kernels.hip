@@ -999,9 +999,9 @@ __global__ void dist_shift_kernel(const DistArgs a, DistWork w)
 // One thread per ELEMENT: it compares its range index with its left neighbour's and writes the few offsets that fall
 // between the two (none at all for 98 % of the elements: a range holds ~49 of them).  Every list is read once, coalesced --
 // the per-offset binary searches of round 1 moved 709 MB per C5 call for 419 MB of lists and ran at the HBM limit.
-__global__ __launch_bounds__(256) void dist_split_kernel(const DistArgs a, DistWork w)
+__global__ __launch_bounds__(256) void dist_split_kernel(const DistArgs a, DistWork w, uint32_t list0)
 {
-    const uint32_t list = blockIdx.x, per = kDistRanges + 1; // lists along x (no 65 535 limit), element blocks along y
+    const uint32_t list = blockIdx.x + list0, per = kDistRanges + 1; // lists along x (no 65 535 limit), element blocks along y
     const bool isq = list < a.nq;
     const uint32_t li = isq ? list : list - a.nq;
     const uint32_t n = isq ? a.q_len[li] : a.r_len[li];
@@ -1257,6 +1257,125 @@ __global__ __launch_bounds__(256) void dist_range_lane_kernel(const DistArgs a, 
         if (j < (int)nwords) dst[j] = acc[j];
 }
 
+// ---- the same all-vs-refs pass without a split pass over the queries (round 3) ------------------------------------------
+// dist_split_kernel reads every list once more just to find where the 1024 ranges begin: as much HBM traffic as the
+// comparison itself.  Here a workgroup takes kDistWalk CONSECUTIVE ranges for its 256 queries, one query per lane: a lane
+// only needs to know where its FIRST range begins (dist_segstart_kernel: one binary search per kDistWalk ranges), walks
+// on from there -- the next range starts where the value's range index changes -- and leaves the range starts behind for
+// the finish kernel (offs_q).  The line a range ends in is still in the lane's registers when the next range begins.
+#ifndef MHX_DIST_WALK
+#define MHX_DIST_WALK 4
+#endif
+constexpr uint32_t kDistWalk = MHX_DIST_WALK;
+
+__global__ __launch_bounds__(256) void dist_segstart_kernel(const DistArgs a, DistWork w)
+{
+    constexpr uint32_t G = kDistRanges / kDistWalk, per = kDistRanges + 1;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.nq * (G + 1)) return;
+    const uint32_t q = id / (G + 1), g = id % (G + 1);
+    const uint32_t n = a.q_len[q], shift = w.params[0];
+    const uint64_t *v = a.q + (uint64_t)q * a.stride;
+    uint32_t lo = 0, hi = n; // first index whose range index (value >> shift) is >= g * kDistWalk
+    if (g == G) lo = n;
+    else if (g != 0) {
+        const uint64_t want = (uint64_t)g * kDistWalk;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((v[mid] >> shift) < want) lo = mid + 1; else hi = mid;
+        }
+    }
+    w.offs_q[q * per + g * kDistWalk] = lo;
+}
+
+__global__ __launch_bounds__(256) void dist_walk_kernel(const DistArgs a, DistWork w)
+{
+    __shared__ unsigned long long keys[kDistTableSlots];
+    __shared__ uint32_t masks[kDistTableSlots];
+    __shared__ uint32_t too_big;
+    constexpr uint32_t G = kDistRanges / kDistWalk, per = kDistRanges + 1;
+    // consecutive workgroups go round the eight XCDs: neighbouring segments of one eighth of the value space on one XCD
+    const uint32_t g = (blockIdx.x & 7u) * (G / 8) + (blockIdx.x >> 3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t shift = w.params[0];
+    const uint32_t q = blockIdx.y * 256 + tid;
+    const bool live = q < a.nq;
+    const uint32_t nwords = (a.nr + 3) / 4;
+    const uint32_t n = live ? a.q_len[q] : 0u;
+    const uint64_t *row = a.q + (uint64_t)(live ? q : 0u) * a.stride;
+    uint32_t i = live ? w.offs_q[q * per + g * kDistWalk] : 0u;
+    uint4 x[4] = {};
+    uint32_t loaded = 0xFFFFFFFFu; // first element of the line held in x
+    auto slot_of = [](uint64_t v) { return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
+    for (uint32_t r = 0; r < kDistWalk; ++r) {
+        const uint32_t p = g * kDistWalk + r;
+        for (int s2 = tid; s2 < kDistTableSlots; s2 += 256) { keys[s2] = kEmptyKey; masks[s2] = 0; }
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (uint32_t rr = 0; rr < a.nr; ++rr) tot += w.offs_r[rr * per + p + 1] - w.offs_r[rr * per + p];
+            too_big = tot > (kDistTableSlots * 3) / 4;
+            if (too_big) atomicOr(&w.params[1], 1u);
+        }
+        __syncthreads();
+        if (too_big) return; // non-uniform input: the host reruns the generic kernel (uniform exit: too_big is shared)
+        for (uint32_t rr = wave; rr < a.nr; rr += 4) { // build: wave w inserts references w, w + 4, ...
+            const uint32_t b = w.offs_r[rr * per + p], e = w.offs_r[rr * per + p + 1];
+            for (uint32_t j = b + lane; j < e; j += 64) {
+                const uint64_t v = a.r[(uint64_t)rr * a.stride + j];
+                uint32_t sl = slot_of(v);
+                for (;;) {
+                    const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
+                    if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << rr); break; }
+                    sl = (sl + 1) & (kDistTableSlots - 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t begin = i;
+            bool more = true; // this lane's walk through range p
+            while (more) {
+                const uint32_t i0 = i & ~7u;
+                if (i0 >= n) break;
+                if (i0 != loaded) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint4 *>(row + i0 + 2 * u);
+                    loaded = i0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t idx = i0 + (uint32_t)u;
+                    if (!more || idx < i) continue;
+                    if (idx >= n) { i = n; more = false; continue; }
+                    const uint4 xv = x[u >> 1];
+                    const uint64_t v = (u & 1) ? (((uint64_t)xv.w << 32) | xv.z) : (((uint64_t)xv.y << 32) | xv.x);
+                    if ((v >> shift) != p) { i = idx; more = false; continue; } // sorted rows: the next range begins here
+                    uint32_t sl = slot_of(v), m = 0;
+                    for (;;) {
+                        const unsigned long long kx = keys[sl];
+                        if (kx == v) { m = masks[sl]; break; }
+                        if (kx == kEmptyKey) break;
+                        sl = (sl + 1) & (kDistTableSlots - 1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) // bits 4j .. 4j+3 of the mask -> the low bit of four bytes
+                        if (j < (int)nwords) acc[j] += (((m >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                }
+                if (more) i = i0 + 8;
+            }
+            if (i > n) i = n;
+            if (i - begin > 255u) atomicOr(&w.params[1], 1u); // a byte counter may have overflowed: not a uniform input
+            uint32_t *dst = reinterpret_cast<uint32_t *>(w.cpart + ((uint64_t)q * kDistRanges + p) * (4 * nwords));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < (int)nwords) dst[j] = acc[j];
+            w.offs_q[q * per + p + 1] = i; // where the next range begins (the finish kernel reads these)
+        }
+        __syncthreads(); // nobody still probes the table that the next round clears
+    }
+}
+
 // 16 pairs per workgroup; thread (seg, pair) first sums its 64 ranges, then the 16 threads of
 // segment 0 locate the cut segment, walk it range by range and finish the cut range with the
 // sequential two-pointer rule.
@@ -1345,10 +1464,23 @@ size_t dist_work_bytes(uint32_t nq, uint32_t nr, size_t *off_q, size_t *off_r, s
 hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t st)
 {
     hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
-    hipLaunchKernelGGL(dist_split_kernel, dim3(a.nq + a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w);
-    static const bool no_lane = getenv("MHX_DIST_NO_LANE") != nullptr;
-    if (a.nq >= 128 && !no_lane) hipLaunchKernelGGL(dist_range_lane_kernel, dim3(kDistRanges, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
-    else hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
+    const bool no_lane = getenv("MHX_DIST_NO_LANE") != nullptr, no_walk = getenv("MHX_DIST_NO_WALK") != nullptr;
+    // rows of whole 64-byte lines (the walk reads a row line by line), enough queries to fill the lanes
+    // (measured: at 1024 queries the walk's 1024 workgroups of four ranges each leave the CUs a third empty and lose 13 % to
+    // split + lane form, 0.48 against 0.42 ms; at 4096 queries they win 5 %, 1.39 against 1.46 ms, and read every query
+    // row once instead of twice -- MHX_DIST_WALK_MIN moves the switch)
+    const uint32_t walk_min = getenv("MHX_DIST_WALK_MIN") ? (uint32_t)atol(getenv("MHX_DIST_WALK_MIN")) : 3072u;
+    const bool walk = !no_lane && !no_walk && a.nq >= walk_min && (a.stride & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.q) & 63) == 0;
+    if (walk) {
+        hipLaunchKernelGGL(dist_split_kernel, dim3(a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w, a.nq); // the references only
+        constexpr uint32_t G = kDistRanges / kDistWalk;
+        hipLaunchKernelGGL(dist_segstart_kernel, dim3((a.nq * (G + 1) + 255) / 256), dim3(256), 0, st, a, w);
+        hipLaunchKernelGGL(dist_walk_kernel, dim3(G, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
+    } else {
+        hipLaunchKernelGGL(dist_split_kernel, dim3(a.nq + a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w, 0u);
+        if (a.nq >= 128 && !no_lane) hipLaunchKernelGGL(dist_range_lane_kernel, dim3(kDistRanges, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
+        else hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
+    }
     const uint32_t pairs = a.nq * a.nr;
     hipLaunchKernelGGL(dist_finish_kernel, dim3((pairs + 15) / 16), dim3(256), 0, st, a, w);
     return hipGetLastError();

@@ -371,6 +371,46 @@ def test_dist_all_vs_refs_fast_path_equals_oracle():
     _check_all_pairs(qrys, refs, 27, s)
 
 
+@pytest.mark.parametrize("form", ["lane", "walk", "wave"])
+def test_dist_one_query_per_lane_forms_equal_oracle(monkeypatch, form):
+    """Batches of >= 128 queries take the range pass with ONE QUERY PER LANE (dist_range_lane_kernel), large ones the walk
+    over consecutive ranges without a split pass over the queries (dist_walk_kernel; forced here by MHX_DIST_WALK_MIN);
+    `wave` is the slice-per-wave kernel of smaller batches on the same data.  Edge cases in the batch: empty and tiny
+    queries, a query equal to a reference, queries that end inside the value space (their last ranges are empty), one
+    whose hashes all lie in the upper half (its first ranges are empty)."""
+    if form == "walk":
+        monkeypatch.setenv("MHX_DIST_WALK_MIN", "128")
+    if form == "wave":
+        monkeypatch.setenv("MHX_DIST_NO_LANE", "1")
+    rng = np.random.default_rng(41)
+    s = 4000
+    base = _sketch_like(rng, s)
+    refs = []
+    for j in range(24):
+        keep = rng.random(len(base)) >= (0.002 * (j + 1) if j < 11 else 0.5)
+        refs.append(np.unique(np.concatenate([base[keep], _sketch_like(rng, int((~keep).sum()))])))
+    qrys = []
+    for i in range(150):
+        src = refs[i % 24]
+        keep = rng.random(len(src)) >= 0.6 * i / 149
+        qrys.append(np.unique(np.concatenate([src[keep], _sketch_like(rng, int((~keep).sum()))])))
+    qrys[5] = refs[5].copy()
+    qrys[6] = qrys[6][:17]
+    qrys[7] = np.zeros(0, np.uint64)
+    qrys[8] = qrys[8][:len(qrys[8]) // 3]                       # ends a third of the way through the value space
+    qrys[9] = qrys[9][qrys[9] >= np.uint64(1 << 63)]            # nothing in the lower half
+    qrys[10] = qrys[10][::7]
+    stride = (max(max(map(len, refs)), max(map(len, qrys))) + 7) // 8 * 8   # rows of whole 64-byte lines (what the walk form asks for)
+    Q, ql = _pad_rows(qrys, stride)
+    R, rl = _pad_rows(refs, stride)
+    common, denom, dist = engine.dist_batch(Q, ql, R, rl, 27, s)
+    for qi in list(range(12)) + list(range(12, 150, 9)):
+        for ri, r in enumerate(refs):
+            c, d, dd = mo.compare(r, qrys[qi], s, 27)
+            assert (common[qi, ri], denom[qi, ri]) == (c, d), (form, qi, ri, len(qrys[qi]))
+            assert dist[qi, ri] == dd
+
+
 def test_dist_non_uniform_values_fall_back_to_the_generic_kernel():
     """All hashes crowded into one narrow value range overflow the per-range LDS table; the
     engine must notice and still return exact results (generic pair kernel)."""
