@@ -507,7 +507,7 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
     // table whatever the input is.
     // Multiplicity filter (m > 1): T cannot follow the data before s hashes with count >= m exist, and until then
     // every admitted k-mer costs two atomics and may be a new table entry.  The first MiB is admitted whole (small
-    // genomes and saturated k-mer spaces show their solid hashes there); after that the bytes seen grow x4 per launch
+    // genomes and saturated k-mer spaces show their solid hashes there); after that the bytes seen grow x8 (m <= 3) or x4 per launch
     // and, in front of every launch, T is capped ON THE DEVICE at 48*s' / (bytes seen after this launch),
     // s' = s + 8*sqrt(s) + 16, i.e. ~20*s admissions per stage -- unless a tighten pass has meanwhile lowered T from
     // solid hashes, or the table looks like a small genome sequenced deeply (cap_threshold_kernel; inside a push the
@@ -523,9 +523,13 @@ static int push_span(mhx_sketcher *sk, const void *d_bytes, uint64_t n, int kfmt
             uint64_t chunk_bytes = next_chunk_bytes;
             if (filtered) {
                 // stages are defined on the bytes actually seen (pushes may be of any size): the uncapped first MiB,
-                // then never more than x4 cumulative growth per launch
+                // then never more than x4 (x8 for m <= 3) cumulative growth per launch
+                // (x8 for m <= 3, round 3: the byte-count cap admits ~19 s' (1 - 1/g) occurrences per stage whatever the growth g
+                // is, and the window of coverages in which s solid hashes lie below the cap -- c / P[Poisson(c) >= m] <= 17:
+                // c in 0.8 .. 16 for m = 3, 1.6 .. 16 for m = 4 -- spans a factor 20 resp. 10: no x8 stage can jump over it.
+                // Two launches and two passes fewer on a 3 GB input.  Larger m keep x4: 2.5 .. 16 for m = 5.)
                 const uint64_t rest_of_prefix = bytes_pushed < kUncappedBytes ? kUncappedBytes - bytes_pushed : 0;
-                chunk_bytes = std::max<uint64_t>(rest_of_prefix, 3 * bytes_pushed);
+                chunk_bytes = std::max<uint64_t>(rest_of_prefix, (sk->m <= 3 ? 7 : 3) * bytes_pushed);
             }
             const uint64_t chunk_tiles = std::max<uint64_t>(1, chunk_bytes / kTileBytes);
             if (chunk_tiles < p.take) p.take = (uint32_t)chunk_tiles;
