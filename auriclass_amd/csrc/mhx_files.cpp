@@ -1027,7 +1027,18 @@ struct FastaInput {
 
 // d_dst != nullptr: the file's raw device buffer is free and large enough -- every reader thread sends what it has read
 // on the copy stream right away (MiB by MiB), so the copy runs beside the reading instead of behind it
+static void load_fasta_input_impl(const char *path, int slot, bool pinned_ok, FastaInput *in, uint8_t *d_dst, size_t d_cap, hipEvent_t ready);
 static void load_fasta_input(const char *path, int slot, bool pinned_ok, FastaInput *in, uint8_t *d_dst, size_t d_cap, hipEvent_t ready)
+{ // runs on a helper thread: nothing may escape it
+    try {
+        load_fasta_input_impl(path, slot, pinned_ok, in, d_dst, d_cap, ready);
+    } catch (const std::exception &e) {
+        in->rc = MHX_E_INTERNAL;
+        in->error = std::string("reading ") + path + ": " + e.what();
+    }
+}
+
+static void load_fasta_input_impl(const char *path, int slot, bool pinned_ok, FastaInput *in, uint8_t *d_dst, size_t d_cap, hipEvent_t ready)
 {
     (void)hipSetDevice(g.device);
     struct stat sb;

@@ -213,3 +213,22 @@ def test_fastq_record_cuts_land_on_record_starts():
             assert all(c in starts or c == len(data) for c in cuts)
             sizes = [b - a for a, b in zip(cuts, cuts[1:])]
             assert max(sizes) <= len(data) // world + 2000
+
+
+def test_first_counted_header_of_a_file(tmp_path):
+    """multigpu.sketch_fastq_files names the reference after the first record mash would count (sequence of >= k bytes),
+    read from the head of the first file, plain or gzipped; blanks and tabs split name and comment as in kseq."""
+    import gzip
+
+    recs = (b"@short extra words\nACGT\n+\nIIII\n" +
+            b"@read7\tlane=3 x\n" + b"ACGTACGTACGTACGTACGTACGTACGT\n+\n" + b"I" * 28 + b"\n" +
+            b"@later one\n" + b"C" * 40 + b"\n+\n" + b"I" * 40 + b"\n")
+    plain = tmp_path / "a.fq"
+    plain.write_bytes(recs)
+    gz = tmp_path / "a.fq.gz"
+    gz.write_bytes(gzip.compress(recs))
+    for p in (plain, gz):
+        assert multigpu._first_counted_header(p, 21) == ("read7", "lane=3 x")
+        assert multigpu._first_counted_header(p, 4) == ("short", "extra words")
+        assert multigpu._first_counted_header(p, 35) == ("later", "one")
+        assert multigpu._first_counted_header(p, 64) == ("short", "extra words")   # none is long enough: the very first header
