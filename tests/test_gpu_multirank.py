@@ -37,6 +37,8 @@ def _seqs(fq_bytes):
 def _exchange(sk, form, k, s, m):
     """`device`: sizes first, data-sized slabs, merge on the GPU (gloo only carries the bytes); `host`: the
     callback form with the host merge (what the CPU tests of the decision logic run)."""
+    if form == "device-cuda":   # the buffers the collective moves live in HBM, as under RCCL (gloo stages them through the host)
+        return multigpu.exchange_and_merge_device(sk, torch.device("cuda", 0))
     if form.startswith("device"):
         return multigpu.exchange_and_merge_device(sk, torch.device("cpu"))
     return multigpu.exchange_and_merge(sk.threshold(), sk.export, k, s, m, torch.device("cpu"))
@@ -77,7 +79,7 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rat
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("form", ["device", "device-table", "host"])
+@pytest.mark.parametrize("form", ["device", "device-cuda", "device-table", "host"])
 @pytest.mark.parametrize("world,k,s,m", [(2, 21, 1000, 1), (2, 21, 1000, 3), (3, 27, 5000, 2), (3, 16, 3000, 2)])
 def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, s, m, form):
     from oracle import mash_oracle as mo
