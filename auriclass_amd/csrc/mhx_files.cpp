@@ -406,6 +406,7 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
     // a big single-member .gz (what sequencers write) is decoded by several threads (mhx_pinflate.cpp); what follows its
     // first member, small files and anything the parallel decoder declines go through the sequential decoder
     std::unique_ptr<ParallelGunzip> par;
+    size_t par_base = 0; // where in the file the member that `par` decodes begins
     std::unique_ptr<BgzfReader> bgzf; // bgzip output: independent blocks of <= 64 KiB, decoded side by side
     if (own) {
         if (!zfile.open(path, GzInflater::kInputPad)) { st->error = std::string("ERROR: could not open ") + path + " for reading"; q->producer_done(); return; }
@@ -468,11 +469,17 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
             } else if (par) {
                 const size_t r = par->read(d + n, kIngestChunk - n);
                 if (r == (size_t)-1) got = -1;
-                else if (r == 0) { // end of the first member (CRC and length verified): the rest, if any, sequentially
-                    const size_t off = par->consumed_input(), zn = zfile.size();
+                else if (r == 0) { // end of a member (CRC and length verified): a further large member (`cat a.gz b.gz`) gets the
+                                   // threads again, anything else goes to the sequential decoder
+                    const size_t off = par_base + par->consumed_input(), zn = zfile.size();
                     par.reset();
-                    inf.set_input(zfile.data() + off, zn - off);
                     produced = 0;
+                    if (off < zn) {
+                        par.reset(new ParallelGunzip());
+                        if (par->start(zfile.data() + off, zn - off, decode_threads)) { par_base = off; continue; }
+                        par.reset();
+                    }
+                    inf.set_input(zfile.data() + off, zn - off);
                     continue;
                 } else {
                     got = (long)r;

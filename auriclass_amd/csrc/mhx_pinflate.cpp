@@ -833,22 +833,26 @@ extern "C" int mhx_gunzip_buffer_mt(const void *gz, size_t n, void *out, size_t 
             }
             off = bgzf.consumed_input();
         }
-        ParallelGunzip par;
         bool declined = false;
-        if (off == 0 && threads >= 2 && par.start(in.data(), n, threads)) {
+        // every large member in turn (`cat a.gz b.gz`): the first one that the multi-threaded decoder does not take, and
+        // everything behind it, goes to the sequential decoder below
+        while (off < n && threads >= 2 && !declined) {
+            ParallelGunzip par;
+            if (!par.start(in.data() + off, n - off, threads)) break;
+            const size_t total_before = total;
             std::vector<uint8_t> piece(4u << 20);
             for (;;) {
                 const size_t room = dst && total < cap ? cap - total : 0;
                 const size_t got = room >= piece.size() ? par.read(dst + total, room) : par.read(piece.data(), piece.size());
                 if (got == (size_t)-1) {
-                    if (par.error().find("memory bound") != std::string::npos) { total = 0; declined = true; break; } // the sequential decoder streams it
+                    if (par.error().find("memory bound") != std::string::npos) { total = total_before; declined = true; break; } // the sequential decoder streams it
                     return fail(MHX_E_FORMAT, "gunzip: %s", par.error().c_str());
                 }
                 if (got == 0) break;
                 if (room < piece.size() && dst && total < cap) memcpy(dst + total, piece.data(), std::min(got, cap - total));
                 total += got;
             }
-            off = declined ? 0 : par.consumed_input();
+            if (!declined) off += par.consumed_input();
         }
         // further members (or everything, when the parallel decoder declined): the sequential decoder
         if (off < n) {

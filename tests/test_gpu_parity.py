@@ -1090,6 +1090,26 @@ def test_long_read_fastq_gz_through_the_chunked_ingest(tmp_path, monkeypatch):
     assert got.comment == ref.comment()
 
 
+def test_concatenated_gzip_members_through_the_ingest(tmp_path, monkeypatch):
+    """`cat a.fq.gz b.fq.gz > ab.fq.gz` is one file of two members (mash reads it through gzread like any other): each large
+    member gets the decoding threads in turn, a small one in between goes through the sequential decoder, and a record
+    may be cut by a member border."""
+    import gzip
+
+    monkeypatch.setenv("MHX_PINFLATE_MIN", "1000000")
+    genome = synth.make_genome(300_000, seed=51)
+    a = synth.make_fastq(genome, 150_000, 150, seed=52, device="cpu").numpy().tobytes()   # 47 MB
+    cut = len(a) // 2 + 77                                   # inside a record
+    tiny = b"@t1\n" + genome[:60].tobytes() + b"\n+\n" + b"I" * 60 + b"\n"
+    p = tmp_path / "ab.fq.gz"
+    p.write_bytes(gzip.compress(a[:cut], 1) + gzip.compress(a[cut:], 6) + gzip.compress(tiny, 9))
+    engine.sketch_files([p], 21, 2000, tmp_path / "o.msh", reads=True, min_mult=2)
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    ref, (want, _) = oracle_sketch(a + tiny, 21, 2000, 2)
+    assert np.array_equal(got.hashes, want)
+    assert got.comment == ref.comment()
+
+
 def test_record_without_qualities_in_front_of_a_tile_border(tmp_path):
     """'@h / SEQ / @h2 ...': kseq reads a record without qualities.  When the cut record's sequence line straddles a tile
     border, every tile's own first lines look regular; the chain check over the tiles' phases refuses the 4-line path

@@ -263,7 +263,7 @@ def test_parallel_gunzip_equals_zlib(lib, monkeypatch):
         co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strategy)
         z = b"".join(co.compress(text[i:i + 700_000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(text), 700_000)) + co.flush()
         assert engine.gunzip(z, 4) == text, strategy
-    # several members: the first one in parallel, the others behind it; then trailing padding
+    # several members (`cat a.gz b.gz`): every large one gets the threads, the small ones the sequential decoder; then trailing padding
     parts = [text[:5_000_000], b"", text[5_000_000:9_000_000], text[9_000_000:]]
     blob = b"".join(_gz(p, 6, filename="r.fq", mtime=7) for p in parts)
     assert engine.gunzip(blob, 4) == b"".join(parts)
