@@ -55,13 +55,14 @@ hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor = nullptr, uint32_t order_log2 = 0,
                           uint64_t *hdr_dev = nullptr, uint64_t *hdr_host = nullptr, uint32_t *ticket = nullptr,
-                          uint64_t *occ_out = nullptr, uint32_t nhdr = 4);
+                          uint64_t *occ_out = nullptr, uint32_t nhdr = 4, uint64_t *hdr_copy = nullptr);
 
 // sharded path: the other ranks' gathered partial results go into this rank's candidate table (slab_insert_kernel)
 constexpr uint32_t kMaxMergeRanks = 64; // ranks per launch (more: several launches)
 struct SlabMergeArgs {
-    const uint64_t *slabs;  // device: nranks slabs of slab_words 8-byte words each: hashes[cap] | counts u32[cap]
+    const uint64_t *slabs;  // device: nranks slabs of slab_words 8-byte words each: [hdr_words of header] hashes[cap] | counts u32[cap]
     uint64_t slab_words, cap;
+    uint32_t hdr_words;
     uint64_t n[kMaxMergeRanks]; // valid entries of each slab (0: skip)
     uint32_t nranks, own_rank;  // own_rank: slab to skip (already in the table); >= nranks: none
     uint64_t t_min;
@@ -77,8 +78,9 @@ hipError_t launch_slab_insert(const SlabMergeArgs &a, uint64_t max_n, hipStream_
 // sharded path, the usual case: the gathered slabs are binned by value and merged bin by bin in LDS (mhx_merge.hip)
 constexpr uint32_t kMergeMaxBins = 16384, kMergeMaxSlots = 4096; // LDS: 2 x 4 bytes per bin in the scatter pass, 12 per slot in the bin pass
 struct MergeArgs {
-    const uint64_t *slabs;      // device: nranks slabs of slab_words 8-byte words each: hashes[cap] | counts u32[cap]
+    const uint64_t *slabs;      // device: nranks slabs of slab_words 8-byte words each: [hdr_words of header] hashes[cap] | counts u32[cap]
     uint64_t slab_words, cap;
+    uint32_t hdr_words;
     uint64_t n[kMaxMergeRanks]; // valid entries of each slab
     uint32_t nranks;
     uint32_t min_mult;

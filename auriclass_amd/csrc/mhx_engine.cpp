@@ -1033,7 +1033,8 @@ extern "C" int mhx_sketcher_export_pack(mhx_sketcher *sk, void *dst, uint64_t ca
 }
 
 static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_device, uint32_t n_ranks, uint64_t cap_entries,
-                            const uint64_t *headers, uint32_t own_rank, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
+                            const uint64_t *headers, uint32_t own_rank, uint64_t *hashes, uint32_t *counts, uint32_t *n_out,
+                            uint32_t hdr_words = 0)
 {
     clear_error();
     int rc = require_engine();
@@ -1056,7 +1057,7 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
     rc = check_flags(flags); // a full table or a malformed FASTQ on ANY rank
     if (rc) return rc;
     if ((others || n_ranks > 1) && !slabs) return fail(MHX_E_ARG, "null slabs");
-    const uint64_t slab_words = cap_entries + cap_entries / 2;
+    const uint64_t slab_words = hdr_words + cap_entries + cap_entries / 2;
     const uint64_t *d_slabs = (const uint64_t *)slabs;
     if (!slabs_on_device && (others || headers[8 * (size_t)own_rank])) {
         const size_t bytes = (size_t)n_ranks * slab_words * sizeof(uint64_t);
@@ -1106,7 +1107,7 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
                 HIPCHK(hipMalloc((void **)&sk->d_mg_cnts, want * sizeof(uint32_t)));
                 sk->mg_entries = want;
             }
-            a.slabs = d_slabs; a.slab_words = slab_words; a.cap = cap_entries; a.nranks = n_ranks; a.min_mult = sk->m; a.t_min = t_min; a.nbins = nbins;
+            a.slabs = d_slabs; a.slab_words = slab_words; a.cap = cap_entries; a.hdr_words = hdr_words; a.nranks = n_ranks; a.min_mult = sk->m; a.t_min = t_min; a.nbins = nbins;
             uint64_t max_all = 0;
             for (uint32_t r = 0; r < kMaxMergeRanks; ++r) { a.n[r] = r < n_ranks ? headers[8 * (size_t)r] : 0; max_all = a.n[r] > max_all ? a.n[r] : max_all; }
             a.cursor = sk->d_mg_small; a.qn = sk->d_mg_small + kMergeMaxBins; a.flags = sk->d_mg_small + 2 * kMergeMaxBins;
@@ -1151,7 +1152,7 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
         std::vector<uint32_t> ac;
         for (uint32_t r = 0; r < n_ranks; ++r) {
             const uint64_t n = headers[8 * (size_t)r], mk = headers[8 * (size_t)r + 3];
-            const uint64_t *hp = hbuf.data() + (size_t)r * slab_words;
+            const uint64_t *hp = hbuf.data() + (size_t)r * slab_words + hdr_words;
             const uint32_t *cp = reinterpret_cast<const uint32_t *>(hp + cap_entries);
             ah.insert(ah.end(), hp, hp + n);
             ac.insert(ac.end(), cp, cp + n);
@@ -1167,6 +1168,7 @@ static int merge_slabs_impl(mhx_sketcher *sk, const void *slabs, int slabs_on_de
         a.slabs = d_slabs + (size_t)r0 * slab_words;
         a.slab_words = slab_words;
         a.cap = cap_entries;
+        a.hdr_words = hdr_words;
         a.nranks = n_ranks - r0 < kMaxMergeRanks ? n_ranks - r0 : kMaxMergeRanks;
         for (uint32_t r = 0; r < kMaxMergeRanks; ++r) a.n[r] = r < a.nranks ? headers[8 * (size_t)(r0 + r)] : 0;
         a.own_rank = own_rank >= r0 && own_rank - r0 < a.nranks ? own_rank - r0 : kMaxMergeRanks;
@@ -1192,6 +1194,61 @@ extern "C" int mhx_sketcher_merge_slabs(mhx_sketcher *sk, const void *slabs, int
         return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_slabs: out of host memory");
     } catch (const std::exception &e) {
         return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_slabs: %s", e.what());
+    }
+}
+
+// ---- the same exchange in ONE collective when the slabs live on the device (RCCL) -----------------------------------
+// The 64-byte header rides in front of the slab: [header8 | hashes[cap] | counts u32[cap]], cap = the caller's guess (the
+// last exchange's sizes, or 4 s + 4096 the first time).  mhx_sketcher_export_into writes the shard's partial result
+// straight into the caller's send buffer -- no separate compaction buffer, no pack step --, the ranks all-gather the
+// slabs, and mhx_sketcher_merge_gathered reads the gathered headers back itself: sizes first is then "sizes with", and
+// only when some rank holds more entries than the guess does the caller repeat with the capacity that call reports
+// (*need_cap; every rank sees the same headers and takes the same turn).
+extern "C" int mhx_sketcher_export_into(mhx_sketcher *sk, void *d_slab, uint64_t cap_entries, uint64_t *header8)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !d_slab || !header8 || cap_entries == 0 || (cap_entries & 1) || cap_entries > 0xFFFFFFF0ull) return fail(MHX_E_ARG, "export_into: null argument or bad capacity");
+    if (sk->merged) return fail(MHX_E_ARG, "this sketcher holds a merged table: mhx_sketcher_reset() first");
+    rc = settle(sk);
+    if (rc) return rc;
+    uint64_t *w = (uint64_t *)d_slab, *d = sk->d_exp_hdr;
+    HIPCHK(launch_extract(table_args(sk), 0, 1, w + 8, (uint32_t *)(w + 8 + cap_entries), (uint32_t)cap_entries, (uint32_t *)d, d + 2, sk->d_thresh, d + 1, d + 3,
+                          g.stream, nullptr, 0, d, sk->h_exp_hdr, sk->d_done, d + 4, 8, w));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < 8; ++i) header8[i] = sk->h_exp_hdr[i];
+    sk->exported = header8[0];
+    sk->export_valid = true;
+    sk->last_T = header8[1];
+    return MHX_OK;
+}
+
+extern "C" int mhx_sketcher_merge_gathered(mhx_sketcher *sk, const void *d_slabs, uint32_t n_ranks, uint64_t cap_entries, uint32_t own_rank,
+                                           uint64_t *hashes, uint32_t *counts, uint32_t *n_out, uint64_t *need_cap)
+{
+    clear_error();
+    int rc = require_engine();
+    if (rc) return rc;
+    if (!sk || !d_slabs || !hashes || !n_out || !need_cap || n_ranks == 0 || (cap_entries & 1)) return fail(MHX_E_ARG, "merge_gathered: null argument or odd capacity");
+    *need_cap = 0;
+    try {
+        const uint64_t slab_words = 8 + cap_entries + cap_entries / 2;
+        std::vector<uint64_t> headers((size_t)n_ranks * 8);
+        // the gathered headers: 64 bytes at the front of every slab
+        HIPCHK(hipMemcpy2DAsync(headers.data(), 64, d_slabs, slab_words * sizeof(uint64_t), 64, n_ranks, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        uint64_t max_n = 0;
+        for (uint32_t r = 0; r < n_ranks; ++r) max_n = std::max(max_n, headers[8 * (size_t)r]);
+        if (max_n > cap_entries) { // some slab is cut short: the caller repeats the exchange with room for all of it
+            *need_cap = max_n;
+            return fail(MHX_E_CAPACITY, "merge_gathered: a shard holds %llu entries, the slabs %llu", (unsigned long long)max_n, (unsigned long long)cap_entries);
+        }
+        return merge_slabs_impl(sk, d_slabs, 1, n_ranks, cap_entries, headers.data(), own_rank, hashes, counts, n_out, 8);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_gathered: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_sketcher_merge_gathered: %s", e.what());
     }
 }
 

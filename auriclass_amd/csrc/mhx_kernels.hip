@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
                                                             uint64_t *limit_out, uint64_t *maxkey_out,
                                                             uint32_t *order_cursor, uint32_t order_log2,
                                                             uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket,
-                                                            uint64_t *occ_out, uint32_t nhdr)
+                                                            uint64_t *occ_out, uint32_t nhdr, uint64_t *hdr_copy)
 {
     if (limit_dev) limit = *limit_dev; // the admission threshold as it stands on the device
     const int bucket_shift = order_shift(limit, order_log2);
@@ -662,6 +662,7 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
     if (threadIdx.x < nhdr) {
         const uint64_t v = __hip_atomic_load(&hdr_dev[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hdr_host[threadIdx.x] = v;
+        if (hdr_copy) hdr_copy[threadIdx.x] = v; // the shard export: the header also rides in front of the slab
         __hip_atomic_store(&hdr_dev[threadIdx.x], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) *ticket = 0;
@@ -670,13 +671,13 @@ __global__ __launch_bounds__(256) void table_extract_kernel(const TableArgs a, u
 hipError_t launch_extract(const TableArgs &a, uint64_t limit, uint32_t min_count, uint64_t *out_keys,
                           uint32_t *out_cnts, uint32_t cap, uint32_t *out_n, uint64_t *flags_out, const uint64_t *limit_dev,
                           uint64_t *limit_out, uint64_t *maxkey_out, hipStream_t st, uint32_t *order_cursor, uint32_t order_log2,
-                          uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket, uint64_t *occ_out, uint32_t nhdr)
+                          uint64_t *hdr_dev, uint64_t *hdr_host, uint32_t *ticket, uint64_t *occ_out, uint32_t nhdr, uint64_t *hdr_copy)
 {
     uint64_t blocks = (a.nslots + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(table_extract_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, limit, min_count, out_keys,
                        out_cnts, cap, out_n, flags_out, limit_dev, limit_out, maxkey_out, order_cursor, order_log2,
-                       hdr_dev, hdr_host, ticket, occ_out, nhdr);
+                       hdr_dev, hdr_host, ticket, occ_out, nhdr, hdr_copy);
     return hipGetLastError();
 }
 
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void slab_insert_kernel(const SlabMergeArgs a)
     }
     if (r == a.own_rank) return;
     const uint64_t n = a.n[r];
-    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
+    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words + a.hdr_words;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(hashes + a.cap);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(a.keys);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kScatterThreads) void merge_scatter_kernel(const Me
     const uint64_t i0 = (uint64_t)blockIdx.x * kMergeChunk;
     if (i0 >= n) return;
     const uint64_t i1 = i0 + kMergeChunk < n ? i0 + kMergeChunk : n;
-    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words;
+    const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words + a.hdr_words;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(hashes + a.cap);
     for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();

@@ -112,6 +112,8 @@ def load() -> ctypes.CDLL:
     L.mhx_sketcher_export_slab.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32]
     L.mhx_sketcher_export_begin.argtypes = [c.c_void_p, c.c_void_p]
     L.mhx_sketcher_export_pack.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64]
+    L.mhx_sketcher_export_into.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]
+    L.mhx_sketcher_merge_gathered.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint64, c.c_uint32, c.c_void_p, c.c_void_p, u32p, u64p]
     L.mhx_sketcher_merge_slabs.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_uint32, c.c_uint64, c.c_void_p, c.c_uint32,
                                            c.c_void_p, c.c_void_p, u32p]
     L.mhx_gunzip_buffer.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t)]
@@ -330,6 +332,27 @@ class Sketcher:
         _check(load().mhx_sketcher_merge_slabs(self._h, ctypes.c_void_p(slabs_ptr), int(on_device), n_ranks, cap_entries,
                                                headers.ctypes.data, own_rank, hashes.ctypes.data, counts.ctypes.data, ctypes.byref(n)))
         return hashes[:n.value].copy(), counts[:n.value].copy()
+
+    def export_into(self, device_ptr: int, cap_entries: int) -> np.ndarray:
+        """One-collective form of the exchange (device buffers): the partial result straight into the send slab
+        [header8 | hashes[cap_entries] | counts u32[cap_entries]] at `device_ptr`; returns the header."""
+        hdr = np.zeros(8, dtype=np.uint64)
+        _check(load().mhx_sketcher_export_into(self._h, ctypes.c_void_p(device_ptr), cap_entries, hdr.ctypes.data))
+        return hdr
+
+    def merge_gathered(self, slabs_ptr: int, n_ranks: int, cap_entries: int, own_rank: int):
+        """Merges the gathered header-carrying slabs on the device.  Returns (hashes, counts, 0), or (None, None, need)
+        when some shard holds `need` > cap_entries entries: repeat export_into / all-gather with a larger capacity."""
+        hashes = np.zeros(self.s, dtype=np.uint64)
+        counts = np.zeros(self.s, dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        need = ctypes.c_uint64(0)
+        rc = load().mhx_sketcher_merge_gathered(self._h, ctypes.c_void_p(slabs_ptr), n_ranks, cap_entries, own_rank,
+                                                hashes.ctypes.data, counts.ctypes.data, ctypes.byref(n), ctypes.byref(need))
+        if rc == MHX_E_CAPACITY and need.value:
+            return None, None, int(need.value)
+        _check(rc)
+        return hashes[:n.value].copy(), counts[:n.value].copy(), 0
 
     def export(self, limit: int) -> Tuple[np.ndarray, np.ndarray]:
         cap = 1 << 16

@@ -138,11 +138,14 @@ def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.
          runs the ordinary extraction: nothing is sorted or merged on the host, whatever m and s are.
     Same exactness rule as finish(), decided from gathered data only, so every rank raises InexactShardedSketch
     together.  The sketcher's table holds the union afterwards: reset() it before the next push."""
+    import os
     import time
 
     world, rank = dist.get_world_size(), dist.get_rank()
     on_device = device.type == "cuda"
-    sk.sync()   # the shard's own sketch kernels (export_begin would wait for them anyway): not part of the exchange's time
+    sk.sync()   # the shard's own sketch kernels (the export would wait for them anyway): not part of the exchange's time
+    if on_device and os.environ.get("MHX_EXCHANGE_SIZES_FIRST") != "1":
+        return _exchange_one_collective(sk, device, world, rank)
     t0 = time.perf_counter()
     hdr = sk.export_begin()
     t1 = time.perf_counter()
@@ -151,11 +154,7 @@ def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.
     _all_gather_flat(all_hdr_t, mine)
     all_hdr = all_hdr_t.cpu().numpy().view(np.uint64).reshape(world, 8)
     t2 = time.perf_counter()
-    flags = 0
-    for r in range(world):
-        flags |= int(all_hdr[r, 2]) & DEVICE_FLAG_MASK & ~0x8
-    if flags:
-        raise RuntimeError(f"device flags {flags:#x} raised during sketching (table full / malformed FASTQ)")
+    _raise_on_device_flags(all_hdr)
     max_n = int(all_hdr[:, 0].max())
     cap = max(1024, (max_n + 1023) // 1024 * 1024)
     words = cap + cap // 2
@@ -176,8 +175,63 @@ def exchange_and_merge_device(sk, device: torch.device) -> Tuple[np.ndarray, np.
     t5 = time.perf_counter()
     last_exchange.update(export_ms=(t1 - t0) * 1e3, sizes_ms=(t2 - t1) * 1e3, pack_ms=(t3 - t2) * 1e3, gather_ms=(t4 - t3) * 1e3,
                          merge_ms=(t5 - t4) * 1e3, total_ms=(t5 - t0) * 1e3, entries_per_rank=[int(x) for x in all_hdr[:, 0]],
-                         slab_bytes=words * 8)
+                         slab_bytes=words * 8, collectives=2)
     return result
+
+
+def _raise_on_device_flags(all_hdr: np.ndarray) -> None:
+    flags = 0
+    for r in range(all_hdr.shape[0]):
+        flags |= int(all_hdr[r, 2]) & DEVICE_FLAG_MASK & ~0x8
+    if flags:
+        raise RuntimeError(f"device flags {flags:#x} raised during sketching (table full / malformed FASTQ)")
+
+
+_cap_guess: dict = {}   # (s, m, world) -> slab capacity that held the last exchange's largest shard, with room
+
+
+def _exchange_one_collective(sk, device: torch.device, world: int, rank: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Device-resident slabs (RCCL): the sizes ride in front of the slabs.  `sk.export_into` compacts the shard's partial
+    result STRAIGHT into the send buffer [header8 | hashes[cap] | counts[cap]] (no separate compaction buffer, no pack
+    step), ONE all-gather moves the slabs, `sk.merge_gathered` reads the gathered headers back and merges on the device.
+    `cap` is a guess: what held the last exchange of this (s, m, world), 4 s + 4096 the first time; it is derived from
+    gathered data only, so that every rank arrives at the same number.  If some rank holds more than that, every rank learns so from the same gathered headers and the exchange is
+    repeated once with room for the largest shard -- the explicit sizes-first round only where it is needed.  Saves a
+    collective, two host round trips and two copies per exchange (0.07 ms of 0.18 on one rank)."""
+    import time
+
+    key = (sk.s, sk.m, world)
+    cap = _cap_guess.get(key, (4 * sk.s + 4096 + 1023) // 1024 * 1024)
+    t0 = time.perf_counter()
+    t_export = t_gather = 0.0
+    for attempt in range(3):
+        words = 8 + cap + cap // 2
+        send = _buffer("send1", words, device)
+        ta = time.perf_counter()
+        hdr = sk.export_into(send.data_ptr(), cap)
+        tb = time.perf_counter()
+        recv = _buffer("recv1", world * words, device)
+        _all_gather_flat(recv, send)
+        torch.cuda.current_stream(device).synchronize()   # the merge runs on the engine's own stream
+        tc = time.perf_counter()
+        t_export += tb - ta
+        t_gather += tc - tb
+        try:
+            hashes, counts, need = sk.merge_gathered(recv.data_ptr(), world, cap, rank)
+        except engine.EngineError as e:
+            if e.code == engine.MHX_E_CAPACITY:
+                raise InexactShardedSketch(e.code, e.message) from None
+            raise
+        if not need:
+            _cap_guess[key] = cap   # (never from this rank's own size: every rank must arrive at the same capacity)
+            t1 = time.perf_counter()
+            last_exchange.update(export_ms=t_export * 1e3, sizes_ms=0.0, pack_ms=0.0, gather_ms=t_gather * 1e3,
+                                 merge_ms=(t1 - tc) * 1e3, total_ms=(t1 - t0) * 1e3, entries_per_rank=None, slab_bytes=words * 8,
+                                 collectives=attempt + 1)
+            return hashes, counts
+        cap = max(1024, (need * 5 // 4 + 1023) // 1024 * 1024)   # the same number on every rank: same headers
+        _cap_guess[key] = cap
+    raise RuntimeError("sharded exchange: slab capacity kept growing")
 
 
 def sharded_sketch(push: Callable[[object], None], k: int, s: int, min_mult: int, expected_bytes: int, device: torch.device,

@@ -168,7 +168,9 @@ def main() -> None:
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    # RCCL moves device-resident slabs (one collective per exchange); gloo carries host tensors (MHX_DIST_TENSORS=cuda:
+    # device tensors under gloo too, to rehearse the RCCL form of the exchange on a one-GPU box)
+    comm_dev = dev if backend == "nccl" or os.environ.get("MHX_DIST_TENSORS") == "cuda" else torch.device("cpu")
     use_dist = world > 1 or os.environ.get("MHX_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on one GPU
     if use_dist:
         import torch.distributed as dist

@@ -154,6 +154,18 @@ int mhx_sketcher_export_pack(mhx_sketcher *sk, void *dst, uint64_t cap_entries);
 int mhx_sketcher_merge_slabs(mhx_sketcher *sk, const void *slabs, int slabs_on_device, uint32_t n_ranks,
                              uint64_t cap_entries, const uint64_t *headers, uint32_t own_rank, uint64_t *hashes,
                              uint32_t *counts, uint32_t *n_out);
+/* The same exchange in ONE collective, for slabs that live on the device (RCCL): the header rides in front of the slab,
+ * [header8 | hashes[cap_entries] | counts u32[cap_entries]] = 8 + cap_entries + cap_entries / 2 words.
+ * mhx_sketcher_export_into compacts the shard's partial result straight into the caller's send buffer (header8 as for
+ * export_begin; entries beyond cap_entries are counted in [0] but not stored).  After the all-gather,
+ * mhx_sketcher_merge_gathered reads the headers back, and either merges (as mhx_sketcher_merge_slabs) or, when some shard
+ * holds more entries than the slabs have room for, returns MHX_E_CAPACITY with *need_cap = the largest n_r: every rank
+ * gets the same answer from the same gathered headers and repeats both calls with a larger cap_entries.  *need_cap == 0
+ * with MHX_E_CAPACITY is the exactness rule's verdict (re-sketch with a larger budget_scale). */
+int mhx_sketcher_export_into(mhx_sketcher *sk, void *d_slab, uint64_t cap_entries, uint64_t *header8);
+int mhx_sketcher_merge_gathered(mhx_sketcher *sk, const void *d_slabs, uint32_t n_ranks, uint64_t cap_entries,
+                                uint32_t own_rank, uint64_t *hashes, uint32_t *counts, uint32_t *n_out,
+                                uint64_t *need_cap);
 int mhx_merge_partials(const uint64_t *hashes, const uint32_t *counts, uint64_t n, uint32_t s,
                        uint32_t min_mult, uint64_t *out_hashes, uint32_t *out_counts, uint32_t *n_out);
 /* bits a shard adds to word [2] of its slab besides the device flags (diagnostics of the m > 1 phase) */

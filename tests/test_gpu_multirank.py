@@ -67,7 +67,9 @@ def _worker(rank, world, port, k, s, m, n_reads, out_dir, form="device", sub_rat
     np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
     if form.startswith("device"):
-        np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array(multigpu.last_exchange["entries_per_rank"]))
+        np.save(os.path.join(out_dir, f"x{rank}.npy"), np.array([multigpu.last_exchange.get("collectives", 0)]))
+        if multigpu.last_exchange.get("entries_per_rank") is not None:   # (the one-collective form does not bring them to the host)
+            np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array(multigpu.last_exchange["entries_per_rank"]))
         # the table now holds the union: pushing without a reset must be refused, after a reset the sketcher is as new
         with pytest.raises(engine.EngineError):
             sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
@@ -98,6 +100,20 @@ def test_sharded_gpu_sketch_plus_exchange_equals_the_oracle(tmp_path, world, k, 
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
         assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), bf_c), f"rank {r}: summed multiplicities"
+
+
+def test_one_collective_exchange_repeats_with_room_for_the_largest_shard(tmp_path):
+    """Device-resident slabs: the first guess of the slab capacity (4 s + 4096) is too small for these shards (3 % substitutions,
+    m = 3: ~30 error k-mers per solid one), every rank learns so from the gathered headers, and the exchange is repeated once."""
+    from oracle import mash_oracle as mo
+
+    world, k, s, m, n_reads, sub_rate = 2, 21, 1000, 3, 60_000, 0.03
+    mp.spawn(_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path), "device-cuda", sub_rate), nprocs=world, join=True)
+    bf_h, bf_c = mo.bruteforce_sketch(_seqs(_input(n_reads, sub_rate).tobytes()), k, s, m)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), bf_h)
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), bf_c)
+        assert int(np.load(tmp_path / f"x{r}.npy")[0]) == 2   # collectives of the first exchange: guess, then room for all
 
 
 def test_exchange_whose_shards_exceed_a_fixed_slab(tmp_path):

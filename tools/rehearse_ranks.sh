@@ -12,3 +12,5 @@ sleep 2; python bench.py --gpus $n --reads 1250000 --steps 10 --warmup 3 > $out/
 sleep 2; python bench.py --gpus $n --reads 1250000 --steps 10 --warmup 3 --m 3 > $out/r03_rehearsal_${n}ranks_k21_s1000_m3.json
 sleep 2; python bench.py --gpus $n --reads 1250000 --steps 10 --warmup 3 --k 27 --s 50000 --m 3 > $out/r03_rehearsal_${n}ranks_k27_s50000_m3.json
 sleep 2; python bench.py --gpus $n --total-reads $((n * 1250000)) --steps 10 --warmup 3 > $out/r03_rehearsal_${n}ranks_strong_k21_s1000_m1.json
+# the RCCL form of the exchange (device-resident slabs, one collective) with gloo as the carrier
+sleep 2; MHX_DIST_TENSORS=cuda python bench.py --gpus $n --reads 1250000 --steps 10 --warmup 3 --k 27 --s 50000 --m 3 > $out/r03_rehearsal_${n}ranks_k27_s50000_m3_device_slabs.json
