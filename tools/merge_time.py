@@ -78,6 +78,31 @@ for k, s, m in ((21, 1000, 1), (21, 1000, 3), (27, 50000, 3)):
         t3 = time.perf_counter()
         t_exp.append((t1 - t0) * 1e3); t_pack.append((t2 - t1) * 1e3); t_merge.append((t3 - t2) * 1e3)
     ok = np.array_equal(got_h, want_h) and np.array_equal(got_c, want_c)
+    # the one-collective form (device-resident slabs under RCCL): header-carrying slabs, export straight into the send buffer
+    words2 = 8 + cap + cap // 2
+    gathered2 = torch.zeros(N * words2, dtype=torch.int64, device="cuda")
+    hdr_t = torch.from_numpy(hdrs.view(np.int64).copy()).to("cuda")
+    for r in range(N):
+        gathered2[r * words2:r * words2 + 8] = hdr_t[r]
+        gathered2[r * words2 + 8:(r + 1) * words2] = gathered[r * words:(r + 1) * words]
+    send2 = torch.empty(words2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    t_exp2, t_merge2 = [], []
+    for _ in range(args.iters + 1):
+        sk.reset()
+        sk.push_device(shard0.data_ptr(), shard0.numel(), engine.FMT_FASTQ4)
+        sk.sync()
+        t0 = time.perf_counter()
+        h0 = sk.export_into(send2.data_ptr(), cap)
+        t1 = time.perf_counter()
+        gathered2[:words2] = send2          # (what the all-gather would do with this rank's slab)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        g2_h, g2_c, need = sk.merge_gathered(gathered2.data_ptr(), N, cap, 0)
+        t3 = time.perf_counter()
+        assert need == 0
+        t_exp2.append((t1 - t0) * 1e3); t_merge2.append((t3 - t2) * 1e3)
+    ok = ok and np.array_equal(g2_h, want_h) and np.array_equal(g2_c, want_c)
     # the host merge of round 2 on the same partials
     host = gathered.cpu().numpy()
     hh = [host[r * words:r * words + int(hdrs[r][0])].view(np.uint64) for r in range(N)]
@@ -90,7 +115,9 @@ for k, s, m in ((21, 1000, 1), (21, 1000, 3), (27, 50000, 3)):
     med = statistics.median
     print(f"k={k} s={s} m={m} ranks={N} reads/rank={args.reads}: entries/rank {[int(x[0]) for x in hdrs][:3]}..., slab {words * 8 / 1e6:.2f} MB/rank | "
           f"export {med(t_exp[1:]):.3f} ms, pack {med(t_pack[1:]):.3f} ms, device merge+extract {med(t_merge[1:]):.3f} ms "
-          f"(sum {med(t_exp[1:]) + med(t_pack[1:]) + med(t_merge[1:]):.3f} ms) | host merge (round 2) {min(t_host):.2f} ms | "
+          f"(sum {med(t_exp[1:]) + med(t_pack[1:]) + med(t_merge[1:]):.3f} ms) | one-collective form: export into the send slab "
+          f"{med(t_exp2[1:]):.3f} ms, merge {med(t_merge2[1:]):.3f} ms (sum {med(t_exp2[1:]) + med(t_merge2[1:]):.3f} ms) | "
+          f"host merge (round 2) {min(t_host):.2f} ms | "
           f"merged == one sketcher over all shards: {ok and np.array_equal(ref_h, want_h)}", flush=True)
     sk.close()
-    del gathered, shard0, parts
+    del gathered, gathered2, shard0, parts
