@@ -1074,6 +1074,27 @@ def test_long_read_fastq_takes_the_look_back_repair_pass(lo, hi, m):
     assert st2["lines"] == 4 * len(reads) and st2["kmers"] == st["kmers"]
 
 
+def test_pushed_buffer_may_be_reused_after_sync_not_before(tmp_path):
+    """include/mhx.h: a pushed span has to stay valid and unchanged until sync() / finish() has returned -- long-read FASTQ
+    is read a second time by the repair pass those calls start.  After sync() the caller may overwrite the buffer: the
+    sketch must be that of the original bytes."""
+    import torch
+
+    rng = np.random.default_rng(9)
+    genome = synth.make_genome(200_000, seed=33).tobytes()
+    reads, data = _long_read_fastq(rng, genome, 300, 2000, 30_000)   # every tile of these reads needs the look-back pass
+    buf = torch.frombuffer(bytearray(data + b"\0" * 64), dtype=torch.uint8).cuda()
+    sk = engine.Sketcher(21, 2000, 1, expected_bytes=len(data))
+    sk.push_device(buf.data_ptr(), len(data), engine.FMT_FASTQ4, keep=buf)
+    sk.sync()                     # the repair pass has run: the span is the caller's again
+    buf.fill_(ord("N"))
+    torch.cuda.synchronize()
+    got, _ = sk.finish()
+    sk.close()
+    _, (want, _) = oracle_sketch(data, 21, 2000, 1)
+    assert np.array_equal(got, want)
+
+
 def test_long_read_fastq_gz_through_the_chunked_ingest(tmp_path, monkeypatch):
     """The streaming ingest reuses its device slots: the repair pass of a chunk has to run before the slot is refilled."""
     import gzip
