@@ -581,6 +581,18 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
     q->producer_done();
 }
 
+// thread entry of a producer: nothing may escape it (a failed allocation ends the file's stream with an error, not the process)
+void inflate_fastq_guarded(const char *path, int file, bool force_zlib, int decode_threads, ChunkQueue *q, FileIngestState *st)
+{
+    try {
+        inflate_fastq(path, file, force_zlib, decode_threads, q, st);
+    } catch (const std::exception &e) {
+        st->error = std::string("ERROR: reading ") + path + " failed (" + e.what() + ")";
+        q->abort();
+        q->producer_done();
+    }
+}
+
 uint64_t guess_inflated_bytes(const char *path)
 {
     struct stat sb;
@@ -779,7 +791,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         // process may run on divided by the ranks of the node) split over the files that are inflated side by side
         const int budget = ingest_thread_budget();
         const int per_file = std::max(1, budget / (int)std::max<size_t>(1, queued.size()) - 1);
-        for (int i : queued) threads.emplace_back(inflate_fastq, paths[i], i, force_zlib, per_file, &q, &st[i]);
+        for (int i : queued) threads.emplace_back(inflate_fastq_guarded, paths[i], i, force_zlib, per_file, &q, &st[i]);
         IngestChunk c, in_flight[2]; // in_flight[slot]: the host buffer whose copy into that slot may still be running
         uint64_t nchunk = 0;
         auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) { rc = fail(MHX_E_HIP, "%s failed: %s", what, hipGetErrorString(e)); q.abort(); } return e == hipSuccess; };
