@@ -1165,14 +1165,18 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
 // ~40 per ELEMENT ROUND of 64 slices, i.e. a quarter of the instructions per element.  Each lane reads its own row
 // (16-byte loads where the pair is aligned: a 64-byte line serves four loads of the same lane out of L1/L2), the rows
 // of a workgroup's 256 queries are 256 concurrent streams.
-__global__ __launch_bounds__(256) void dist_range_lane_kernel(const DistArgs a, DistWork w)
+#ifndef MHX_DIST_LANE_BLOCK
+#define MHX_DIST_LANE_BLOCK 512
+#endif
+constexpr int kLaneBlock = MHX_DIST_LANE_BLOCK; // queries (= threads) per workgroup: they share one table build
+__global__ __launch_bounds__(kLaneBlock) void dist_range_lane_kernel(const DistArgs a, DistWork w)
 {
     __shared__ unsigned long long keys[kDistTableSlots];
     __shared__ uint32_t masks[kDistTableSlots];
     __shared__ uint32_t too_big;
     const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < kDistTableSlots; i += 256) { keys[i] = kEmptyKey; masks[i] = 0; }
+    for (int i = tid; i < kDistTableSlots; i += kLaneBlock) { keys[i] = kEmptyKey; masks[i] = 0; }
     if (tid == 0) {
         uint32_t tot = 0;
         for (uint32_t r = 0; r < a.nr; ++r) tot += w.offs_r[r * per + p + 1] - w.offs_r[r * per + p];
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(256) void dist_range_lane_kernel(const DistArgs a, 
     __syncthreads();
     if (too_big) return;
     auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
-    for (uint32_t r = wave; r < a.nr; r += 4) { // build: wave w inserts references w, w + 4, ...
+    for (uint32_t r = wave; r < a.nr; r += kLaneBlock / 64) { // build: wave w inserts references w, w + #waves, ...
         const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
         for (uint32_t i = b + lane; i < e; i += 64) {
             const uint64_t v = a.r[(uint64_t)r * a.stride + i];
@@ -1195,7 +1199,7 @@ __global__ __launch_bounds__(256) void dist_range_lane_kernel(const DistArgs a, 
         }
     }
     __syncthreads();
-    const uint32_t q = blockIdx.y * 256 + tid;
+    const uint32_t q = blockIdx.y * kLaneBlock + tid;
     if (q >= a.nq) return;
     const uint32_t nwords = (a.nr + 3) / 4;
     const uint32_t b = w.offs_q[q * per + p], e = w.offs_q[q * per + p + 1];
@@ -1467,10 +1471,11 @@ hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t 
     hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
     const bool no_lane = getenv("MHX_DIST_NO_LANE") != nullptr, no_walk = getenv("MHX_DIST_NO_WALK") != nullptr;
     // rows of whole 64-byte lines (the walk reads a row line by line), enough queries to fill the lanes
-    // (measured: at 1024 queries the walk's 1024 workgroups of four ranges each leave the CUs a third empty and lose 13 % to
-    // split + lane form, 0.48 against 0.42 ms; at 4096 queries they win 5 %, 1.39 against 1.46 ms, and read every query
-    // row once instead of twice -- MHX_DIST_WALK_MIN moves the switch)
-    const uint32_t walk_min = getenv("MHX_DIST_WALK_MIN") ? (uint32_t)atol(getenv("MHX_DIST_WALK_MIN")) : 3072u;
+    // (measured: at 1024 queries the walk's 1024 workgroups of four ranges each leave the CUs a third empty and lose 20 % to
+    // split + lane form, 0.48 against 0.40 ms; from 4096 queries on the two are within 2-3 % of each other (1.38 / 1.36 ms,
+    // 2.55 / 2.48 at 8192) and the walk reads every query row once instead of twice: it takes over there, leaving the HBM
+    // bandwidth to whatever else runs -- MHX_DIST_WALK_MIN moves the switch)
+    const uint32_t walk_min = getenv("MHX_DIST_WALK_MIN") ? (uint32_t)atol(getenv("MHX_DIST_WALK_MIN")) : 4096u;
     const bool walk = !no_lane && !no_walk && a.nq >= walk_min && (a.stride & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.q) & 63) == 0;
     if (walk) {
         hipLaunchKernelGGL(dist_split_kernel, dim3(a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w, a.nq); // the references only
@@ -1479,7 +1484,7 @@ hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t 
         hipLaunchKernelGGL(dist_walk_kernel, dim3(G, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
     } else {
         hipLaunchKernelGGL(dist_split_kernel, dim3(a.nq + a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w, 0u);
-        if (a.nq >= 128 && !no_lane) hipLaunchKernelGGL(dist_range_lane_kernel, dim3(kDistRanges, (a.nq + 255) / 256), dim3(256), 0, st, a, w);
+        if (a.nq >= 128 && !no_lane) hipLaunchKernelGGL(dist_range_lane_kernel, dim3(kDistRanges, (a.nq + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, a, w);
         else hipLaunchKernelGGL(dist_range_kernel, dim3(kDistRanges, kDistQueryChunks), dim3(256), 0, st, a, w);
     }
     const uint32_t pairs = a.nq * a.nr;
