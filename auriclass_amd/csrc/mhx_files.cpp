@@ -1181,7 +1181,10 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
             }
         }
         if (!any && have_fb) { fname = fb_name; fcomment = fb_comment; }
-        if (kmers == 0 && count == 0) return no_records(paths[0]);
+        // mash stops when no record holds k bases.  (`kmers` is not that question: the device counts every window of k BYTES
+        // inside one line, and a CRLF file of reads one base shorter than k has such windows -- 31 bases and the '\r' --
+        // although none of them is a k-mer.)
+        if (count == 0) return no_records(paths[0]);
         double set_size = 0.0, mult = 0.0;
         if (!ref.hashes.empty()) {
             set_size = pow(2.0, k > 16 ? 64.0 : 32.0) * (double)ref.hashes.size() / (double)ref.hashes.back();

@@ -374,7 +374,7 @@ def sketch_fastq_files(paths, k: int, s: int, min_mult: int, out_msh, device: to
     total = torch.tensor([records[-1] if records else 0], dtype=torch.int64, device=device)
     dist.all_reduce(total, op=dist.ReduceOp.SUM)
     n_records = int(total.item())
-    if n_records == 0 and len(hashes) == 0:
+    if n_records == 0:   # no record holds k bases (the device may still have hashed windows of k BYTES: CRLF reads of k - 1 bases)
         raise engine.NoRecordsError(engine.MHX_E_NO_RECORDS, f'ERROR: Did not find fasta records in "{paths[0]}".')
     set_size = mult = 0.0
     if len(hashes):

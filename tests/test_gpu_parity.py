@@ -1111,6 +1111,32 @@ def test_long_read_fastq_gz_through_the_chunked_ingest(tmp_path, monkeypatch):
     assert got.comment == ref.comment()
 
 
+def test_crlf_reads_one_base_shorter_than_k_are_no_records(tmp_path):
+    """A CRLF FASTQ whose reads hold k - 1 bases: every sequence line has k bytes (the bases and the '\\r'), none has k
+    bases.  mash stops with its "no records" error, and so must the file-level call (found by the randomised sweep)."""
+    k = 32
+    genome = synth.make_genome(20_000, seed=61)
+    data = synth.make_fastq(genome, 500, k - 1, seed=62, device="cpu").numpy().tobytes().replace(b"\n", b"\r\n")
+    ref = mo.Sketcher(k, 1000, 1)
+    ref.add_fastx(data)
+    assert ref.records == 0
+    for name in ("a.fq", "a.fq.gz"):
+        p = tmp_path / name
+        if name.endswith(".gz"):
+            import gzip
+            p.write_bytes(gzip.compress(data))
+        else:
+            p.write_bytes(data)
+        with pytest.raises(engine.NoRecordsError):
+            engine.sketch_files([p], k, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
+    # one base more and the file is sketched
+    ok = synth.make_fastq(genome, 500, k, seed=62, device="cpu").numpy().tobytes().replace(b"\n", b"\r\n")
+    (tmp_path / "b.fq").write_bytes(ok)
+    engine.sketch_files([tmp_path / "b.fq"], k, 1000, tmp_path / "b.msh", reads=True, min_mult=1)
+    _, (want, _) = oracle_sketch(ok, k, 1000, 1)
+    assert np.array_equal(mo.read_msh(tmp_path / "b.msh").references[0].hashes, want)
+
+
 def test_concatenated_gzip_members_through_the_ingest(tmp_path, monkeypatch):
     """`cat a.fq.gz b.fq.gz > ab.fq.gz` is one file of two members (mash reads it through gzread like any other): each large
     member gets the decoding threads in turn, a small one in between goes through the sequential decoder, and a record
