@@ -1173,30 +1173,47 @@ __global__ __launch_bounds__(kLaneBlock) void dist_range_lane_kernel(const DistA
 {
     __shared__ unsigned long long keys[kDistTableSlots];
     __shared__ uint32_t masks[kDistTableSlots];
-    __shared__ uint32_t too_big;
     const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // where range p begins and ends in every reference: lane r of EVERY wave holds reference r's pair (nr <= 32), so each
+    // wave knows the table load by itself and all reference loads of the build are issued together -- two HBM round trips
+    // for the whole build instead of two per reference and wave
+    uint32_t rb = 0, re = 0;
+    if ((uint32_t)lane < a.nr) { rb = w.offs_r[lane * per + p]; re = w.offs_r[lane * per + p + 1]; }
     for (int i = tid; i < kDistTableSlots; i += kLaneBlock) { keys[i] = kEmptyKey; masks[i] = 0; }
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (uint32_t r = 0; r < a.nr; ++r) tot += w.offs_r[r * per + p + 1] - w.offs_r[r * per + p];
-        too_big = tot > (kDistTableSlots * 3) / 4;
-        if (too_big) atomicOr(&w.params[1], 1u);
+    uint32_t tot = re - rb;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
+    if (tot > (kDistTableSlots * 3) / 4) { // the same in every wave: a uniform exit
+        if (tid == 0) atomicOr(&w.params[1], 1u);
+        return;
     }
-    __syncthreads();
-    if (too_big) return;
     auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
-    for (uint32_t r = wave; r < a.nr; r += kLaneBlock / 64) { // build: wave w inserts references w, w + #waves, ...
-        const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
-        for (uint32_t i = b + lane; i < e; i += 64) {
-            const uint64_t v = a.r[(uint64_t)r * a.stride + i];
-            uint32_t sl = slot_of(v);
-            for (;;) {
-                const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
-                if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
-                sl = (sl + 1) & (kDistTableSlots - 1);
-            }
+    auto insert = [&](uint64_t v, uint32_t r) {
+        uint32_t sl = slot_of(v);
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
+            if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
+            sl = (sl + 1) & (kDistTableSlots - 1);
         }
+    };
+    constexpr int kWaves = kLaneBlock / 64, kPerWave = (32 + kWaves - 1) / kWaves;
+    uint64_t rv[kPerWave];
+    uint32_t have = 0;
+#pragma unroll
+    for (int t = 0; t < kPerWave; ++t) { // build: wave w inserts references w, w + #waves, ...; their first 64 elements
+        const uint32_t r = (uint32_t)wave + (uint32_t)kWaves * t;
+        const uint32_t b = __shfl(rb, (int)(r & 31u)), e = __shfl(re, (int)(r & 31u));
+        rv[t] = 0;
+        if (r < a.nr && b + lane < e) { rv[t] = a.r[(uint64_t)r * a.stride + b + lane]; have |= 1u << t; }
+    }
+    __syncthreads(); // the table is clear
+#pragma unroll
+    for (int t = 0; t < kPerWave; ++t)
+        if ((have >> t) & 1u) insert(rv[t], (uint32_t)wave + (uint32_t)kWaves * t);
+    for (uint32_t r = wave; r < a.nr; r += kWaves) { // slices of more than 64 elements (rare with uniform hashes)
+        const uint32_t b = __shfl(rb, (int)r), e = __shfl(re, (int)r);
+        for (uint32_t i = b + 64u + lane; i < e; i += 64) insert(a.r[(uint64_t)r * a.stride + i], r);
     }
     __syncthreads();
     const uint32_t q = blockIdx.y * kLaneBlock + tid;

@@ -383,6 +383,22 @@ MHX_HD void phase_stage(TileSmem &sm, int tid, const uint8_t *base, uint64_t til
 {
     const uint64_t lim = (end + 15) & ~(uint64_t)15; // last readable 16-byte chunk boundary
     constexpr int kChunks = kTileBytes / 16;          // 1024
+#ifndef MHX_STAGE_SERIAL
+    // tile and halo inside the readable span (wave-uniform; every tile but the last): all loads of a lane are issued
+    // before the first LDS write -- behind the per-chunk bound test below hipcc waits for each load (s_waitcnt vmcnt(0))
+    // before it issues the next, four HBM round trips in a row at the head of every tile
+    if (tile_off + (uint64_t)(kTileBytes + kHaloBytes) <= lim) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(base + tile_off) + tid;
+        uint4 v[kChunks / kBlock], h = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < kChunks / kBlock; ++j) v[j] = src[j * kBlock];
+        if (tid < kHaloBytes / 16) h = src[kChunks];
+#pragma unroll
+        for (int j = 0; j < kChunks / kBlock; ++j) sm.bytes[j * kBlock + tid] = v[j];
+        if (tid < kHaloBytes / 16) sm.bytes[kChunks + tid] = h;
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < kChunks / kBlock; ++j) {
         const int c = j * kBlock + tid;
