@@ -273,6 +273,52 @@ def shard_bounds(n_records: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def sharded_dist_batch(q: np.ndarray, q_len: np.ndarray, r: np.ndarray, r_len: np.ndarray, k: int, s: int,
+                       device: torch.device, gather: bool = True,
+                       compute: Optional[Callable[..., Tuple[np.ndarray, np.ndarray, np.ndarray]]] = None
+                       ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Tuple[int, int]]:
+    """Batched distances over the GPUs of a node (`mash dist` is independent per (query, reference) pair,
+    /root/reference/auriclass/classes.py:92-104): rank i compares query rows shard_bounds(nq, world, i) with ALL
+    references (replicated: 24 x 400 KB at AuriClass's defaults) on its own GPU -- no collective on the data path.
+    Returns (common, denom, dist, (lo, hi)).  gather=False: the three arrays hold this rank's rows [lo, hi) only.
+    gather=True: ONE all-gather of the results (16 bytes per pair, rows padded to the largest shard) and every rank
+    returns all [nq, nr] rows.  `compute` (default engine.dist_batch, the HIP path) is a hook for the CPU tests of this
+    sharding logic, which have no GPU to compute on."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    nq, nr = int(q.shape[0]), int(r.shape[0])
+    lo, hi = shard_bounds(nq, world, rank)
+    fn = compute or engine.dist_batch
+    if hi > lo:
+        common, denom, dd = fn(q[lo:hi], q_len[lo:hi], r, r_len, k, s)
+    else:   # more ranks than queries
+        common, denom, dd = (np.zeros((0, nr), np.uint32), np.zeros((0, nr), np.uint32), np.zeros((0, nr), np.float64))
+    if not gather or world == 1:
+        return common, denom, dd, (lo, hi)
+    per = -(-nq // world)   # rows of the largest shard
+    # one int64 payload per pair and plane: plane 0 = (common << 32) | denom, plane 1 = the bits of the f64 distance
+    send = torch.zeros((per, nr, 2), dtype=torch.int64)
+    send[: hi - lo, :, 0] = torch.from_numpy((common.astype(np.int64) << 32) | denom.astype(np.int64))
+    send[: hi - lo, :, 1] = torch.from_numpy(np.ascontiguousarray(dd, dtype=np.float64).view(np.int64))
+    send = send.to(device)
+    out = torch.empty((world, per, nr, 2), dtype=torch.int64, device=device)
+    if device.type == "cuda":
+        dist.all_gather_into_tensor(out.view(-1), send.view(-1))
+    else:
+        dist.all_gather(list(out.unbind(0)), send)
+    out = out.cpu().numpy()
+    all_common = np.zeros((nq, nr), np.uint32)
+    all_denom = np.zeros((nq, nr), np.uint32)
+    all_dist = np.zeros((nq, nr), np.float64)
+    for i in range(world):
+        a, b = shard_bounds(nq, world, i)
+        pk = out[i, : b - a, :, 0]
+        all_common[a:b] = (pk >> 32).astype(np.uint32)
+        all_denom[a:b] = (pk & 0xFFFFFFFF).astype(np.uint32)
+        all_dist[a:b] = np.ascontiguousarray(out[i, : b - a, :, 1]).view(np.float64)
+    return all_common, all_denom, all_dist, (lo, hi)
+
+
 def fastq_record_cuts(data, world: int) -> List[int]:
     """Byte offsets [c_0 = 0, c_1, ..., c_world = len] that cut a 4-line FASTQ held in `data` (bytes, memoryview
     or a uint8 numpy array) into `world` record-aligned shards of roughly equal size: cut r is the first record

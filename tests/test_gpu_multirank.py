@@ -396,3 +396,32 @@ def test_sharded_file_level_sketch_writes_the_single_gpu_msh(tmp_path, kind):
     for r in range(world):
         got = (tmp_path / f"stderr{r}.txt").read_text()
         assert [ln for ln in got.splitlines() if ln.startswith("Estimated")] == want_lines
+
+
+def _dist_worker(rank, world, port, nq, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.test_multigpu_gloo import _dist_inputs
+
+    nr, s, k = 24, 4000, 27
+    Q, q_len, R, r_len = _dist_inputs(nq, nr, s, seed=8)
+    dev = torch.device("cpu")   # gloo carries the small result gather; the comparison runs on the GPU
+    c, d, x, _ = multigpu.sharded_dist_batch(Q, q_len, R, r_len, k, s, dev)
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), c=c, d=d, x=x)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 300), (3, 130)])
+def test_sharded_distances_on_the_gpu_equal_the_oracle(tmp_path, world, nq):
+    """The query rows of a distance batch over 2 and 3 ranks (sharing the one GPU): each rank's rows through the HIP
+    kernels (the one-query-per-lane form at 150 rows, the wave form at 43), the gathered table equal to the oracle's."""
+    from tests.test_multigpu_gloo import _dist_inputs, _oracle_dist
+
+    mp.spawn(_dist_worker, args=(world, _free_port(), nq, str(tmp_path)), nprocs=world, join=True)
+    Q, q_len, R, r_len = _dist_inputs(nq, 24, 4000, seed=8)
+    wc, wd, wx = _oracle_dist(Q, q_len, R, r_len, 27, 4000)
+    for r in range(world):
+        z = np.load(tmp_path / f"d{r}.npz")
+        assert np.array_equal(z["c"], wc) and np.array_equal(z["d"], wd), f"rank {r}"
+        assert np.allclose(z["x"], wx, rtol=1e-12, atol=0), f"rank {r}"   # device log vs libm: a few ulp

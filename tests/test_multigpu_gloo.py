@@ -232,3 +232,66 @@ def test_first_counted_header_of_a_file(tmp_path):
         assert multigpu._first_counted_header(p, 4) == ("short", "extra words")
         assert multigpu._first_counted_header(p, 35) == ("later", "one")
         assert multigpu._first_counted_header(p, 64) == ("short", "extra words")   # none is long enough: the very first header
+
+
+def _dist_inputs(nq, nr, s, seed=5):
+    """nr reference lists and nq queries (ascending unique u64 rows, ragged lengths, one empty query)."""
+    rng = np.random.default_rng(seed)
+    base = np.unique(rng.integers(0, 1 << 63, size=s, dtype=np.uint64))
+    R = np.zeros((nr, s), np.uint64)
+    r_len = np.zeros(nr, np.uint32)
+    for j in range(nr):
+        v = np.unique(np.where(rng.random(len(base)) < 0.05 * (j + 1), rng.integers(0, 1 << 63, size=len(base), dtype=np.uint64), base))
+        R[j, :len(v)], r_len[j] = v, len(v)
+    Q = np.zeros((nq, s), np.uint64)
+    q_len = np.zeros(nq, np.uint32)
+    for i in range(nq):
+        src = R[i % nr, :r_len[i % nr]]
+        v = np.unique(np.where(rng.random(len(src)) < i / (2.0 * nq), rng.integers(0, 1 << 63, size=len(src), dtype=np.uint64), src))
+        if i == 3:
+            v = v[:0]
+        elif i % 4 == 1:
+            v = v[: len(v) // 2]
+        Q[i, :len(v)], q_len[i] = v, len(v)
+    return Q, q_len, R, r_len
+
+
+def _oracle_dist(q, q_len, r, r_len, k, s):
+    from oracle import mash_oracle as mo
+
+    nq, nr = q.shape[0], r.shape[0]
+    common, denom, dd = np.zeros((nq, nr), np.uint32), np.zeros((nq, nr), np.uint32), np.zeros((nq, nr), np.float64)
+    for i in range(nq):
+        for j in range(nr):
+            common[i, j], denom[i, j], dd[i, j] = mo.compare(r[j, :r_len[j]], q[i, :q_len[i]], s, k)
+    return common, denom, dd
+
+
+def _dist_worker(rank, world, port, nq, nr, s, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Q, q_len, R, r_len = _dist_inputs(nq, nr, s)
+    c, d, x, (lo, hi) = multigpu.sharded_dist_batch(Q, q_len, R, r_len, k, s, torch.device("cpu"), compute=_oracle_dist)
+    own = multigpu.sharded_dist_batch(Q, q_len, R, r_len, k, s, torch.device("cpu"), gather=False, compute=_oracle_dist)
+    assert own[0].shape == (hi - lo, nr) and np.array_equal(own[0], c[lo:hi]) and np.array_equal(own[2], x[lo:hi])
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), c=c, d=d, x=x, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 11), (3, 7), (3, 2)])
+def test_sharded_distances_are_the_unsharded_table(tmp_path, world, nq):
+    """distances shard over the query rows with no exchange on the data path; the gathered table on every
+    rank is the unsharded one (ragged shard sizes, an empty query, more ranks than queries).  The comparison itself is
+    the oracle's here (no GPU on this side); tests/test_gpu_multirank.py runs the same call on the HIP path."""
+    engine.build()
+    nr, s, k = 5, 300, 21
+    mp.spawn(_dist_worker, args=(world, _free_port(), nq, nr, s, k, str(tmp_path)), nprocs=world, join=True)
+    Q, q_len, R, r_len = _dist_inputs(nq, nr, s)
+    wc, wd, wx = _oracle_dist(Q, q_len, R, r_len, k, s)
+    covered = np.zeros(nq, bool)
+    for r in range(world):
+        z = np.load(tmp_path / f"d{r}.npz")
+        assert np.array_equal(z["c"], wc) and np.array_equal(z["d"], wd) and np.array_equal(z["x"], wx), f"rank {r}"
+        covered[int(z["lo"]):int(z["hi"])] = True
+    assert covered.all()
