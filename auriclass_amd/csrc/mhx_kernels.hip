@@ -1239,6 +1239,26 @@ __global__ __launch_bounds__(kLaneBlock) void dist_range_lane_kernel(const DistA
         for (int j = 0; j < 8; ++j) // bits 4j .. 4j+3 of the mask -> the low bit of four bytes
             if (j < (int)nwords) acc[j] += (((m >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
     };
+#ifndef MHX_DIST_LINE64
+    if ((reinterpret_cast<uintptr_t>(row) & 127) == 0 && (a.stride & 15u) == 0) {
+        // whole 128-byte L2 lines, both halves consumed at once.  With one 64-byte half per step (the form below, round 3's
+        // first) the lane kernel fetched exactly TWICE the rows' bytes: 65 k lanes per XCD each keep a line and the next in
+        // flight, 8 MB against 4 MB of L2, so the other half of a 128-byte L2 line was gone again before its lane came
+        // back for it.  C5: 830 -> 564 MB fetched by this kernel, 0.388 -> 0.399 ms (16 instead of 8 element slots per
+        // step, more of them masked at the ends of a slice; -DMHX_DIST_LINE64 brings the old form back)
+        for (uint32_t i0 = b & ~15u; i0 < e; i0 += 16) {
+            uint4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const uint4 *>(row + i0 + 2 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + 2 * u;
+                if (i >= b && i < e) one(((uint64_t)x[u].y << 32) | x[u].x);
+                if (i + 1 >= b && i + 1 < e) one(((uint64_t)x[u].w << 32) | x[u].z);
+            }
+        }
+    } else
+#endif
     if ((reinterpret_cast<uintptr_t>(row) & 63) == 0 && (a.stride & 7u) == 0) { // (rows of whole lines: nothing is read beyond a row)
         // whole 64-byte lines, each fetched ONCE by the one lane that needs it (four 16-byte loads issued together; with
         // a load per pair of elements a line was fetched up to four times, and 1500 concurrent streams per CU do not fit
@@ -1326,7 +1346,12 @@ __global__ __launch_bounds__(256) void dist_walk_kernel(const DistArgs a, DistWo
     const uint32_t n = live ? a.q_len[q] : 0u;
     const uint64_t *row = a.q + (uint64_t)(live ? q : 0u) * a.stride;
     uint32_t i = live ? w.offs_q[q * per + g * kDistWalk] : 0u;
-    uint4 x[4] = {};
+#ifndef MHX_DIST_LINE64
+    constexpr uint32_t kLineElems = 16; // a whole 128-byte L2 line per step: both halves are used before it is evicted
+#else
+    constexpr uint32_t kLineElems = 8;
+#endif
+    uint4 x[kLineElems / 2] = {};
     uint32_t loaded = 0xFFFFFFFFu; // first element of the line held in x
     auto slot_of = [](uint64_t v) { return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
     for (uint32_t r = 0; r < kDistWalk; ++r) {
@@ -1358,15 +1383,15 @@ __global__ __launch_bounds__(256) void dist_walk_kernel(const DistArgs a, DistWo
             const uint32_t begin = i;
             bool more = true; // this lane's walk through range p
             while (more) {
-                const uint32_t i0 = i & ~7u;
+                const uint32_t i0 = i & ~(kLineElems - 1u);
                 if (i0 >= n) break;
                 if (i0 != loaded) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint4 *>(row + i0 + 2 * u);
+                    for (int u = 0; u < (int)kLineElems / 2; ++u) x[u] = *reinterpret_cast<const uint4 *>(row + i0 + 2 * u);
                     loaded = i0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < (int)kLineElems; ++u) {
                     const uint32_t idx = i0 + (uint32_t)u;
                     if (!more || idx < i) continue;
                     if (idx >= n) { i = n; more = false; continue; }
@@ -1384,7 +1409,7 @@ __global__ __launch_bounds__(256) void dist_walk_kernel(const DistArgs a, DistWo
                     for (int j = 0; j < 8; ++j) // bits 4j .. 4j+3 of the mask -> the low bit of four bytes
                         if (j < (int)nwords) acc[j] += (((m >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
                 }
-                if (more) i = i0 + 8;
+                if (more) i = i0 + kLineElems;
             }
             if (i > n) i = n;
             if (i - begin > 255u) atomicOr(&w.params[1], 1u); // a byte counter may have overflowed: not a uniform input
@@ -1487,13 +1512,18 @@ hipError_t launch_dist_ranges(const DistArgs &a, const DistWork &w, hipStream_t 
 {
     hipLaunchKernelGGL(dist_shift_kernel, dim3(1), dim3(256), 0, st, a, w);
     const bool no_lane = getenv("MHX_DIST_NO_LANE") != nullptr, no_walk = getenv("MHX_DIST_NO_WALK") != nullptr;
-    // rows of whole 64-byte lines (the walk reads a row line by line), enough queries to fill the lanes
-    // (measured: at 1024 queries the walk's 1024 workgroups of four ranges each leave the CUs a third empty and lose 20 % to
-    // split + lane form, 0.48 against 0.40 ms; from 4096 queries on the two are within 2-3 % of each other (1.38 / 1.36 ms,
-    // 2.55 / 2.48 at 8192) and the walk reads every query row once instead of twice: it takes over there, leaving the HBM
-    // bandwidth to whatever else runs -- MHX_DIST_WALK_MIN moves the switch)
-    const uint32_t walk_min = getenv("MHX_DIST_WALK_MIN") ? (uint32_t)atol(getenv("MHX_DIST_WALK_MIN")) : 4096u;
-    const bool walk = !no_lane && !no_walk && a.nq >= walk_min && (a.stride & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.q) & 63) == 0;
+    // rows of whole 128-byte lines (the walk reads a row line by line), enough queries to fill the lanes.
+    // Measured with 128-byte lines in both forms (C5 rows, profiles/r03_dist_line128_ab.txt): 1024 queries 0.40 ms lane
+    // form / 0.49 walk (1024 workgroups of four ranges each leave the CUs a third empty), 4096: 1.30 / 1.37, 8192: 2.60 /
+    // 2.52 -- the walk takes over there; it fetches 1.9x the algorithmic bytes against the lane form's 2.6x (no split
+    // pass over the queries, but 257 binary searches per row).  MHX_DIST_WALK_MIN moves the switch.
+    const uint32_t walk_min = getenv("MHX_DIST_WALK_MIN") ? (uint32_t)atol(getenv("MHX_DIST_WALK_MIN")) : 8192u;
+    #ifndef MHX_DIST_LINE64
+    const bool whole_lines = (a.stride & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.q) & 127) == 0;
+#else
+    const bool whole_lines = (a.stride & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.q) & 63) == 0;
+#endif
+    const bool walk = !no_lane && !no_walk && a.nq >= walk_min && whole_lines;
     if (walk) {
         hipLaunchKernelGGL(dist_split_kernel, dim3(a.nr, (a.stride + 511) / 512), dim3(256), 0, st, a, w, a.nq); // the references only
         constexpr uint32_t G = kDistRanges / kDistWalk;

@@ -371,7 +371,7 @@ def test_dist_all_vs_refs_fast_path_equals_oracle():
     _check_all_pairs(qrys, refs, 27, s)
 
 
-@pytest.mark.parametrize("form", ["lane", "walk", "wave"])
+@pytest.mark.parametrize("form", ["lane", "lane64", "walk", "wave"])
 def test_dist_one_query_per_lane_forms_equal_oracle(monkeypatch, form):
     """Batches of >= 128 queries take the range pass with ONE QUERY PER LANE (dist_range_lane_kernel), large ones the walk
     over consecutive ranges without a split pass over the queries (dist_walk_kernel; forced here by MHX_DIST_WALK_MIN);
@@ -400,7 +400,11 @@ def test_dist_one_query_per_lane_forms_equal_oracle(monkeypatch, form):
     qrys[8] = qrys[8][:len(qrys[8]) // 3]                       # ends a third of the way through the value space
     qrys[9] = qrys[9][qrys[9] >= np.uint64(1 << 63)]            # nothing in the lower half
     qrys[10] = qrys[10][::7]
-    stride = (max(max(map(len, refs)), max(map(len, qrys))) + 7) // 8 * 8   # rows of whole 64-byte lines (what the walk form asks for)
+    # rows of whole 128-byte L2 lines: what the walk form and the lane form's main path ask for; `lane64`: rows of whole
+    # 64-byte lines only (an odd number of them), the lane form's narrower path
+    stride = (max(max(map(len, refs)), max(map(len, qrys))) + 15) // 16 * 16
+    if form == "lane64":
+        stride += 8
     Q, ql = _pad_rows(qrys, stride)
     R, rl = _pad_rows(refs, stride)
     common, denom, dist = engine.dist_batch(Q, ql, R, rl, 27, s)
