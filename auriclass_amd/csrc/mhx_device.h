@@ -89,6 +89,7 @@ struct MergeArgs {
     uint32_t nbins;             // power of two, 256 .. kMergeMaxBins
     uint32_t region;            // entries a bin's region holds
     uint32_t table_slots;       // LDS table of merge_bin_kernel (power of two, >= 4/3 region)
+    uint32_t chunk;             // slab entries per workgroup of the scatter pass (set by launch_merge_bins)
     uint32_t *cursor;           // [nbins] entries placed per bin; zero between merges (merge_bin_kernel clears it)
     uint32_t *qn;               // [nbins] qualifying entries per bin
     uint32_t *flags;            // [0]: 1 a region overflowed, 2 a table overflowed, 4 too many qualifying entries in a bin; zero between merges

@@ -19,7 +19,10 @@
 
 namespace mhx {
 
-constexpr uint32_t kMergeChunk = 65536;  // slab entries per workgroup of the scatter pass
+// slab entries per workgroup of the scatter pass: small enough that a merge of a few million entries fills the chip (65536,
+// the first choice, gave 8 x 704 k entries 88 workgroups on 256 CUs: 0.31 ms), large enough that the one global atomic
+// per (workgroup, bin) is shared by a few entries
+constexpr uint32_t kMergeChunkDefault = 8192;
 constexpr uint32_t kMergeMaxQual = 1024; // qualifying entries a bin can rank in LDS
 
 constexpr int kScatterThreads = 1024, kScatterBatch = 4; // loads in flight per thread: the passes are chains of HBM round trips otherwise
@@ -30,9 +33,9 @@ __global__ __launch_bounds__(kScatterThreads) void merge_scatter_kernel(const Me
     uint32_t *cnt = smem, *base = smem + a.nbins;
     const uint32_t r = blockIdx.y;
     const uint64_t n = a.n[r];
-    const uint64_t i0 = (uint64_t)blockIdx.x * kMergeChunk;
+    const uint64_t i0 = (uint64_t)blockIdx.x * a.chunk;
     if (i0 >= n) return;
-    const uint64_t i1 = i0 + kMergeChunk < n ? i0 + kMergeChunk : n;
+    const uint64_t i1 = i0 + a.chunk < n ? i0 + a.chunk : n;
     const uint64_t *hashes = a.slabs + (uint64_t)r * a.slab_words + a.hdr_words;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(hashes + a.cap);
     for (uint32_t b = threadIdx.x; b < a.nbins; b += blockDim.x) cnt[b] = 0;
@@ -142,47 +145,73 @@ __global__ __launch_bounds__(256) void merge_bin_kernel(const MergeArgs a)
 }
 
 // out: the sketcher's pinned result block [n, T, flags, 0 | hashes[out_cap] | counts[out_cap]] (the layout finish() reads)
-__global__ __launch_bounds__(256) void merge_compact_kernel(const MergeArgs a, uint64_t *out, uint32_t out_cap)
+constexpr int kCompactThreads = 1024;
+__global__ __launch_bounds__(kCompactThreads) void merge_compact_kernel(const MergeArgs a, uint64_t *out, uint32_t out_cap)
 {
+    constexpr int kWaves = kCompactThreads / 64;
     __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t red[2][kWaves];
     __shared__ uint32_t block_base, grand_total;
+    __shared__ uint32_t s_off[257];
     // every workgroup owns 256 bins and sums the counts of the bins in front of its own
     const uint32_t first = blockIdx.x * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t before = 0, all = 0;
-    for (uint32_t b = threadIdx.x; b < a.nbins; b += 256) { // (nbins <= 16384: at most 64 per thread)
+    for (uint32_t b = threadIdx.x; b < a.nbins; b += kCompactThreads) {
         const uint32_t v = a.qn[b];
         all += v;
         if (b < first) before += v;
     }
-    // workgroup reduction of (before, all)
     for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
-    __shared__ uint32_t red[2][4];
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = all; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        block_base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        grand_total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        uint32_t x = 0, y = 0;
+        for (int w = 0; w < kWaves; ++w) { x += red[0][w]; y += red[1][w]; }
+        block_base = x;
+        grand_total = y;
     }
-    __syncthreads();
+    // exclusive scan of the 256 bins' counts (threads 0 .. 255, one bin each)
     const uint32_t b = first + threadIdx.x;
-    const uint32_t mine = b < a.nbins ? a.qn[b] : 0u;
-    // exclusive scan of `mine` over the workgroup
+    const uint32_t mine = threadIdx.x < 256 && b < a.nbins ? a.qn[b] : 0u;
     uint32_t v = mine;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t u = __shfl_up(v, o);
         if (lane >= o) v += u;
     }
-    if (lane == 63) wave_sums[wave] = v;
+    if (lane == 63 && wave < 4) wave_sums[wave] = v;
     __syncthreads();
-    uint32_t off = block_base + v - mine;
-    for (int w = 0; w < wave; ++w) off += wave_sums[w];
+    if (threadIdx.x < 256) {
+        uint32_t off = block_base + v - mine;
+        for (int w = 0; w < wave; ++w) off += wave_sums[w];
+        s_off[threadIdx.x] = off;
+        if (threadIdx.x == 255) s_off[256] = off + mine;
+    }
+    __syncthreads();
+    // The workgroup copies its bins' entries TOGETHER, entry e by thread e mod 1024, two entries in flight per thread
+    // (coalesced within a bin's run).  Only the first workgroups have anything to copy -- the block holds the first ~s
+    // entries -- so their threads must be many and their loads independent: a thread per bin walking its ~100 entries
+    // one dependent load after the other took 0.14 ms at 8 x 704 k entries, 256 threads with one entry in flight 0.12.
     uint32_t *oc = reinterpret_cast<uint32_t *>(out + 4 + out_cap);
-    for (uint32_t j = 0; j < mine; ++j) {
-        if (off + j >= out_cap) break;
-        out[4 + off + j] = a.sc_keys[(uint64_t)b * a.region + j];
-        oc[off + j] = a.sc_cnts[(uint64_t)b * a.region + j];
+    const uint32_t lo = s_off[0], hi = s_off[256] < out_cap ? s_off[256] : out_cap;
+    auto source = [&](uint32_t e) { // the bin of entry e: the last i with s_off[i] <= e (empty bins share an offset with their successor)
+        uint32_t x = 0, y = 256;
+        while (y - x > 1) {
+            const uint32_t mid = (x + y) >> 1;
+            if (s_off[mid] <= e) x = mid; else y = mid;
+        }
+        return (uint64_t)(first + x) * a.region + (e - s_off[x]);
+    };
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 2 * kCompactThreads) {
+        const uint32_t e2 = e + kCompactThreads;
+        const bool two = e2 < hi;
+        const uint64_t s1 = source(e), s2 = two ? source(e2) : s1;
+        const uint64_t k1 = a.sc_keys[s1], k2 = a.sc_keys[s2];
+        const uint32_t c1 = a.sc_cnts[s1], c2 = a.sc_cnts[s2];
+        out[4 + e] = k1;
+        oc[e] = c1;
+        if (two) { out[4 + e2] = k2; oc[e2] = c2; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[0] = grand_total;
@@ -193,12 +222,15 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeArgs a, u
     }
 }
 
-hipError_t launch_merge_bins(const MergeArgs &a, uint64_t max_n, uint64_t *out, uint32_t out_cap, hipStream_t st)
+hipError_t launch_merge_bins(const MergeArgs &a_in, uint64_t max_n, uint64_t *out, uint32_t out_cap, hipStream_t st)
 {
+    MergeArgs a = a_in;
     if (a.nbins < 256 || a.nbins > kMergeMaxBins || (a.nbins & (a.nbins - 1)) || a.table_slots < 256 || a.table_slots > kMergeMaxSlots ||
         (a.table_slots & (a.table_slots - 1)))
         return hipErrorInvalidValue;
-    const unsigned chunks = (unsigned)((max_n + kMergeChunk - 1) / kMergeChunk);
+    static const uint32_t chunk_knob = getenv("MHX_MERGE_CHUNK") ? (uint32_t)atol(getenv("MHX_MERGE_CHUNK")) : 0u; // experiment knob
+    a.chunk = chunk_knob >= 1024 ? chunk_knob : kMergeChunkDefault;
+    const unsigned chunks = (unsigned)((max_n + a.chunk - 1) / a.chunk);
     const size_t scatter_lds = 2 * (size_t)a.nbins * sizeof(uint32_t);
     const size_t bin_lds = (size_t)a.table_slots * 12 + (size_t)kMergeMaxQual * 12;
     static bool attr_set = false; // dynamic LDS beyond 64 KB has to be asked for once per kernel
@@ -210,7 +242,7 @@ hipError_t launch_merge_bins(const MergeArgs &a, uint64_t max_n, uint64_t *out, 
     }
     if (chunks) hipLaunchKernelGGL(merge_scatter_kernel, dim3(chunks, a.nranks), dim3(kScatterThreads), scatter_lds, st, a);
     hipLaunchKernelGGL(merge_bin_kernel, dim3(a.nbins), dim3(256), bin_lds, st, a);
-    hipLaunchKernelGGL(merge_compact_kernel, dim3(a.nbins / 256), dim3(256), 0, st, a, out, out_cap);
+    hipLaunchKernelGGL(merge_compact_kernel, dim3(a.nbins / 256), dim3(kCompactThreads), 0, st, a, out, out_cap);
     return hipGetLastError();
 }
 
