@@ -628,23 +628,24 @@ static int ensure_pinned_ring()
 // reads [off, off + len) of fd into dst with `nthreads` parallel preads; false on a short read
 static bool parallel_pread(int fd, uint8_t *dst, uint64_t off, size_t len, int nthreads)
 {
-    std::vector<std::thread> th;
+    JoinedThreads th;
     std::vector<int> ok((size_t)nthreads, 1);
     const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
     for (int t = 0; t < nthreads; ++t) {
         const size_t b = (size_t)t * per;
         if (b >= len) break;
         const size_t e = std::min(len, b + per);
-        th.emplace_back([=, &ok]() {
+        auto part = [=, &ok]() {
             size_t done = b;
             while (done < e) {
                 const ssize_t got = pread(fd, dst + done, e - done, (off_t)(off + done));
                 if (got <= 0) { ok[(size_t)t] = 0; return; }
                 done += (size_t)got;
             }
-        });
+        };
+        if (!th.spawn(part)) part(); // no thread to be had: this one reads the part itself
     }
-    for (auto &t : th) t.join();
+    th.join();
     for (int v : ok) if (!v) return false;
     return true;
 }
@@ -785,13 +786,19 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
     }
     if (!rc && !fallback && !queued.empty()) {
         ChunkQueue q(2 * queued.size() + 4);
-        std::vector<std::thread> threads;
+        // (joined on every way out of this block; declared behind the queue they feed, so they are gone before it is)
+        JoinedThreads threads;
+        struct AbortOnExit { ChunkQueue &q; bool armed = true; ~AbortOnExit() { if (armed) { q.abort(); (void)hipStreamSynchronize(g.copy_stream); (void)hipStreamSynchronize(g.stream); } } } abort_guard{q}; // an exception in the loop below: the producers must not wait for room for ever
         for (size_t j = 0; j < queued.size(); ++j) q.producer_started();
         // decoding threads per .gz file: the host's share (ingest_thread_budget: MHX_INGEST_THREADS, else the cores this
         // process may run on divided by the ranks of the node) split over the files that are inflated side by side
         const int budget = ingest_thread_budget();
         const int per_file = std::max(1, budget / (int)std::max<size_t>(1, queued.size()) - 1);
-        for (int i : queued) threads.emplace_back(inflate_fastq_guarded, paths[i], i, force_zlib, per_file, &q, &st[i]);
+        for (int i : queued) {
+            if (threads.spawn(inflate_fastq_guarded, paths[i], i, force_zlib, per_file, &q, &st[i])) continue;
+            q.producer_done(); // this file has no producer: give up on the call
+            if (!rc) { rc = fail(MHX_E_INTERNAL, "could not start an ingest thread"); q.abort(); }
+        }
         IngestChunk c, in_flight[2]; // in_flight[slot]: the host buffer whose copy into that slot may still be running
         uint64_t nchunk = 0;
         auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) { rc = fail(MHX_E_HIP, "%s failed: %s", what, hipGetErrorString(e)); q.abort(); } return e == hipSuccess; };
@@ -823,7 +830,8 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         if (rc) hipStreamSynchronize(g.stream); // nothing may still read the slots or the buffers when we leave
         in_flight[0].release();
         in_flight[1].release();
-        for (auto &t : threads) t.join();
+        threads.join();
+        abort_guard.armed = false;
     }
     bool own_failed = false;
     for (auto &f : st) own_failed = own_failed || f.own_inflate_failed;
@@ -1069,14 +1077,14 @@ static void load_fasta_input_impl(const char *path, int slot, bool pinned_ok, Fa
             const bool stream = d_dst && len + 64 <= d_cap;
             const int nthreads = len >= (4u << 20) ? std::min(8, ingest_thread_budget()) : 1;
             uint8_t *dst = g.pinned[slot];
-            std::vector<std::thread> th;
+            JoinedThreads th;
             std::vector<int> good((size_t)nthreads, 1);
             const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
             for (int t = 0; ok && t < nthreads; ++t) {
                 const size_t b = (size_t)t * per;
                 if (b >= len) break;
                 const size_t e = std::min(len, b + per);
-                th.emplace_back([=, &good]() {
+                auto part = [=, &good]() {
                     (void)hipSetDevice(g.device);
                     size_t done = b, sent = b;
                     while (done < e) {
@@ -1088,9 +1096,10 @@ static void load_fasta_input_impl(const char *path, int slot, bool pinned_ok, Fa
                             sent = done;
                         }
                     }
-                });
+                };
+                if (!th.spawn(part)) part(); // no thread to be had: this one reads the part itself
             }
-            for (auto &t : th) t.join();
+            th.join();
             for (int v : good) ok = ok && v;
             close(fd);
             if (ok && stream) ok = hipEventRecord(ready, g.copy_stream) == hipSuccess;
@@ -1217,11 +1226,17 @@ static int mhx_sketch_files_impl(const char *const *paths, int n_paths, int k, u
         auto raw_of = [&](int i) { return stream_ok ? g.fasta.d_raw[i & 1] : (uint8_t *)nullptr; };
         std::thread loader;
         struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{loader};
+        auto start_loader = [&](int j) { // file j on its way while file j - 1 is on the GPU; without a thread to be had: loaded here and now
+            try {
+                loader = std::thread(load_fasta_input, paths[j], j % Engine::kPinnedSlots, pinned_ok, &inputs[j], raw_of(j), g.fasta.raw_cap, g.fasta.raw_ready[j & 1]);
+            } catch (const std::system_error &) {
+                load_fasta_input(paths[j], j % Engine::kPinnedSlots, pinned_ok, &inputs[j], raw_of(j), g.fasta.raw_cap, g.fasta.raw_ready[j & 1]);
+            }
+        };
         load_fasta_input(paths[0], 0, pinned_ok, &inputs[0], raw_of(0), g.fasta.raw_cap, g.fasta.raw_ready[0]);
         for (int i = 0; i < n_paths; ++i) {
             if (loader.joinable()) loader.join();
-            if (i + 1 < n_paths) loader = std::thread(load_fasta_input, paths[i + 1], (i + 1) % Engine::kPinnedSlots, pinned_ok, &inputs[i + 1],
-                                                      raw_of(i + 1), g.fasta.raw_cap, g.fasta.raw_ready[(i + 1) & 1]);
+            if (i + 1 < n_paths) start_loader(i + 1);
             FastaInput &in = inputs[i];
             err += std::string("Sketching ") + paths[i] + "...\n";
             if (in.rc) return fail(in.rc, "%s", in.error.c_str());

@@ -2,6 +2,9 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <system_error>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/mhx.h"
@@ -132,5 +135,29 @@ double binomial_cdf(uint64_t x, double p, uint64_t n);        // P[X <= x]
 double binomial_sf_ge(uint64_t x, double p, uint64_t n);      // P[X >= x]
 std::string fmt_g(double v);
 std::string bounds_text(int k, double prob);
+
+// Worker threads that are joined whatever happens: a std::thread destroyed while joinable ends the process in
+// std::terminate, so neither an exception between creation and join nor a thread that could not be created (spawn
+// returns false: the caller does that share of the work itself, or gives up) may leave one behind.
+struct JoinedThreads {
+    std::vector<std::thread> t;
+    template <class... A> bool spawn(A &&...a)
+    {
+        try {
+            t.emplace_back(std::forward<A>(a)...);
+            return true;
+        } catch (const std::system_error &) {
+            return false;
+        } catch (const std::bad_alloc &) {
+            return false;
+        }
+    }
+    void join()
+    {
+        for (auto &x : t)
+            if (x.joinable()) x.join();
+    }
+    ~JoinedThreads() { join(); }
+};
 
 } // namespace mhx

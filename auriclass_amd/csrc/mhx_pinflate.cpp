@@ -774,7 +774,11 @@ bool BgzfReader::start(const uint8_t *z, size_t n, int threads)
     for (size_t g = 0; g < ngroups; ++g) p.left[g] = (uint32_t)std::min(Impl::kGroup, p.blocks.size() - g * Impl::kGroup);
     p.slot.resize(Impl::kSlots);
     for (auto &s : p.slot) s.resize(Impl::kGroup * 65536);
-    for (int t = 0; t < threads; ++t) p.workers.emplace_back([&p] { p.worker(); });
+    try {
+        for (int t = 0; t < threads; ++t) p.workers.emplace_back([&p] { p.worker(); });
+    } catch (const std::system_error &) { // the host would not give us another thread: the ones we have do the work
+        if (p.workers.empty()) { p.blocks.clear(); p.group_bytes.clear(); return false; } // none at all: the sequential decoder
+    }
     return true;
 }
 
