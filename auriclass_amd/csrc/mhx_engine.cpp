@@ -81,6 +81,9 @@ extern "C" void mhx_shutdown(void)
     hipFree(g.fasta.d_out); hipFree(g.fasta.d_ws); hipFree(g.fasta.d_seps);
     if (g.fasta.h_words) hipHostFree(g.fasta.h_words);
     hipFree(g.dist_ws);
+    if (g.dist_img) hipHostFree(g.dist_img);
+    g.dist_img = nullptr;
+    g.dist_img_cap = 0;
     hipFree(g.dist_in);
     for (void *p : g.ingest_pinned) hipHostFree(p);
     for (int i = 0; i < 2; ++i) {
@@ -1338,15 +1341,18 @@ static int dist_stage(size_t bytes, uint8_t **out)
     return MHX_OK;
 }
 
-extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r, const uint32_t *r_len,
-                              uint32_t nr, uint32_t stride, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist,
-                              int device_ptrs)
+// q_rows / r_rows (host form only): the rows where they lie, one pointer each (q / r are then unused) -- mhx_dist_files
+// hands over the hash lists inside its pinned image of the reference sketch file instead of building padded matrices
+static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r, const uint32_t *r_len,
+                           uint32_t nr, uint32_t stride, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist,
+                           int device_ptrs, const uint64_t *const *q_rows, const uint64_t *const *r_rows)
 {
     clear_error();
     int rc = require_engine();
     if (rc) return rc;
     if (nq == 0 || nr == 0) return MHX_OK;
-    if (!q || !q_len || !r || !r_len || !common || !denom) return fail(MHX_E_ARG, "null argument");
+    if ((!q && !q_rows) || !q_len || (!r && !r_rows) || !r_len || !common || !denom) return fail(MHX_E_ARG, "null argument");
+    if (device_ptrs && (q_rows || r_rows)) return fail(MHX_E_ARG, "row pointers are a host form");
     if (k < 1 || k > 32 || s == 0 || stride == 0) return fail(MHX_E_ARG, "bad k / s / stride");
     const uint64_t pairs = (uint64_t)nq * nr;
     if (pairs > 0x7FFFFFFFull) return fail(MHX_E_ARG, "too many pairs for one call");
@@ -1368,7 +1374,12 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
         dd = (uint32_t *)(drl + brl + bo);
         // rows that are mostly padding travel one by one (valid prefix only), full ones as one block
         hipError_t ce = hipSuccess;
-        auto rows = [&](uint8_t *dst, const uint64_t *src, const uint32_t *len, uint32_t n) {
+        auto rows = [&](uint8_t *dst, const uint64_t *src, const uint32_t *len, uint32_t n, const uint64_t *const *ptrs) {
+            if (ptrs) { // every row from its own place
+                for (uint32_t i = 0; i < n && ce == hipSuccess; ++i)
+                    if (len[i]) ce = hipMemcpyAsync(dst + (size_t)i * stride * 8, ptrs[i], (size_t)len[i] * 8, hipMemcpyHostToDevice, g.stream);
+                return;
+            }
             uint64_t valid = 0;
             for (uint32_t i = 0; i < n; ++i) valid += len[i];
             if (n > 64 || valid * 2 >= (uint64_t)n * stride) {
@@ -1378,8 +1389,8 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
             for (uint32_t i = 0; i < n && ce == hipSuccess; ++i)
                 if (len[i]) ce = hipMemcpyAsync(dst + (size_t)i * stride * 8, src + (size_t)i * stride, (size_t)len[i] * 8, hipMemcpyHostToDevice, g.stream);
         };
-        rows(dq, q, q_len, nq);
-        rows(dr, r, r_len, nr);
+        rows(dq, q, q_len, nq, q_rows);
+        rows(dr, r, r_len, nr, r_rows);
         if (ce == hipSuccess) ce = hipMemcpyAsync(dql, q_len, (size_t)nq * 4, hipMemcpyHostToDevice, g.stream);
         if (ce == hipSuccess) ce = hipMemcpyAsync(drl, r_len, (size_t)nr * 4, hipMemcpyHostToDevice, g.stream);
         if (ce != hipSuccess) return fail(MHX_E_HIP, "H2D copy failed in dist_batch: %s", hipGetErrorString(ce));
@@ -1470,6 +1481,31 @@ extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t
     }
     return MHX_OK;
 }
+
+extern "C" int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const uint64_t *r, const uint32_t *r_len,
+                              uint32_t nr, uint32_t stride, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist,
+                              int device_ptrs)
+{
+    try {
+        return dist_batch_core(q, q_len, nq, r, r_len, nr, stride, k, s, common, denom, dist, device_ptrs, nullptr, nullptr);
+    } catch (const std::bad_alloc &) {
+        return fail(MHX_E_INTERNAL, "mhx_dist_batch: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MHX_E_INTERNAL, "mhx_dist_batch: %s", e.what());
+    }
+}
+
+namespace mhx {
+int dist_batch_rows(const uint64_t *const *q_rows, const uint32_t *q_len, uint32_t nq, const uint64_t *const *r_rows, const uint32_t *r_len,
+                    uint32_t nr, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist)
+{
+    uint32_t stride = 16;
+    for (uint32_t i = 0; i < nq; ++i) stride = q_len[i] > stride ? q_len[i] : stride;
+    for (uint32_t i = 0; i < nr; ++i) stride = r_len[i] > stride ? r_len[i] : stride;
+    stride = (stride + 15u) & ~15u; // rows of whole 128-byte lines on the device
+    return dist_batch_core(nullptr, q_len, nq, nullptr, r_len, nr, stride, k, s, common, denom, dist, 0, q_rows, r_rows);
+}
+} // namespace mhx
 
 extern "C" int mhx_sketcher_finish(mhx_sketcher *sk, uint64_t *hashes, uint32_t *counts, uint32_t *n_out)
 {

@@ -21,6 +21,11 @@ struct RefSketch {
     uint64_t length = 0;
     std::vector<uint64_t> hashes; // ascending; values < 2^32 when the sketch uses 32-bit hashes
     std::vector<uint32_t> counts; // optional (empty unless present in the file)
+    // msh_parse_image(..., views = true): a 64-bit hash list stays where it is in the caller's file image (`hashes` empty)
+    const uint64_t *view = nullptr;
+    uint32_t view_n = 0;
+    const uint64_t *hash_data() const { return view ? view : hashes.data(); }
+    size_t hash_count() const { return view ? view_n : hashes.size(); }
 };
 struct SketchSet {
     uint32_t kmer_size = 0, sketch_size = 0, window_size = 0, hash_seed = 42;
@@ -30,9 +35,17 @@ struct SketchSet {
     std::vector<RefSketch> refs;
     bool use64() const { return kmer_size > 16; } // 4^k > 2^32
 };
+// batched distances with every row where it lies in host memory (mhx_engine.cpp; see dist_batch_core)
+int dist_batch_rows(const uint64_t *const *q_rows, const uint32_t *q_len, uint32_t nq, const uint64_t *const *r_rows, const uint32_t *r_len,
+                    uint32_t nr, int k, uint32_t s, uint32_t *common, uint32_t *denom, double *dist);
 int msh_serialize(const SketchSet &s, std::vector<uint8_t> &out);
 int msh_write_file(const char *path, const SketchSet &s);
 int msh_read_file(const char *path, SketchSet &s);
+// The container held in memory.  views: 64-bit hash lists are not copied out (RefSketch::view points into `raw`, which
+// must be 8-byte aligned and outlive `s`), and their order is NOT checked here -- the caller does that (check_ascending),
+// over the references in parallel if it likes.  `path` only names the file in messages.
+int msh_parse_image(const uint8_t *raw, size_t n, const char *path, SketchSet &s, bool views);
+bool check_ascending(const uint64_t *h, size_t n);
 
 // ---- FASTA/FASTQ ingest (mhx_fastx.cpp) -------------------------------------------------
 int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);

@@ -213,6 +213,13 @@ struct Reader {
 };
 } // namespace
 
+bool check_ascending(const uint64_t *h, size_t n)
+{
+    for (size_t j = 1; j < n; ++j)
+        if (h[j] <= h[j - 1]) return false;
+    return true;
+}
+
 int msh_read_file(const char *path, SketchSet &s)
 {
     std::vector<uint8_t> raw;
@@ -224,6 +231,12 @@ int msh_read_file(const char *path, SketchSet &s)
     raw.resize(sz > 0 ? (size_t)sz : 0);
     if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); return fail(MHX_E_IO, "cannot read %s", path); }
     fclose(f);
+    return msh_parse_image(raw.data(), raw.size(), path, s, false);
+}
+
+int msh_parse_image(const uint8_t *raw_data, size_t raw_size, const char *path, SketchSet &s, bool views)
+{
+    struct { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; } } raw{raw_data, raw_size};
     if (raw.size() < 16) return fail(MHX_E_FORMAT, "%s is not a mash sketch (too short)", path);
     uint32_t nseg;
     memcpy(&nseg, raw.data(), 4);
@@ -231,17 +244,24 @@ int msh_read_file(const char *path, SketchSet &s)
     if (nseg == 0 || nseg > 65536 || 4 + 4 * (size_t)nseg > raw.size()) return fail(MHX_E_FORMAT, "%s is not a mash sketch (segment table)", path);
     size_t off = 4 + 4 * (size_t)nseg;
     if (off % 8) off += 4;
-    // the file buffer is 8-byte aligned relative to its start only if `off` is; copy words out
-    std::vector<std::vector<uint64_t>> store(nseg);
+    // segments are read as 8-byte words: where they are, if the image is 8-byte aligned (the segments start at a multiple
+    // of 8 bytes from its start), else from copies
+    const bool in_place = (reinterpret_cast<uintptr_t>(raw.data()) & 7u) == 0;
+    if (!in_place) views = false;
+    std::vector<std::vector<uint64_t>> store(in_place ? 0 : nseg);
     Reader rd;
     for (uint32_t i = 0; i < nseg; ++i) {
         uint32_t w;
         memcpy(&w, raw.data() + 4 + 4 * i, 4);
         if (off + (size_t)w * 8 > raw.size()) return fail(MHX_E_FORMAT, "%s is truncated", path);
-        store[i].resize(w);
-        if (w) memcpy(store[i].data(), raw.data() + off, (size_t)w * 8);
+        if (in_place) {
+            rd.seg.push_back(reinterpret_cast<const uint64_t *>(raw.data() + off));
+        } else {
+            store[i].resize(w);
+            if (w) memcpy(store[i].data(), raw.data() + off, (size_t)w * 8);
+            rd.seg.push_back(store[i].data());
+        }
         off += (size_t)w * 8;
-        rd.seg.push_back(store[i].data());
         rd.words.push_back(w);
     }
     Reader::Target root = rd.resolve(0, 0);
@@ -284,7 +304,8 @@ int msh_read_file(const char *path, SketchSet &s)
                 if (h64.ok) {
                     const uint32_t n = h64.hi >> 3;
                     if ((h64.hi & 7) != 5 || !rd.in(h64.seg, h64.word, n)) return fail(MHX_E_FORMAT, "%s: bad hash list", path);
-                    r.hashes.assign(rd.seg[h64.seg] + h64.word, rd.seg[h64.seg] + h64.word + n);
+                    if (views) { r.view = rd.seg[h64.seg] + h64.word; r.view_n = n; }
+                    else r.hashes.assign(rd.seg[h64.seg] + h64.word, rd.seg[h64.seg] + h64.word + n);
                 } else if (h32.ok) {
                     const uint32_t n = h32.hi >> 3;
                     if ((h32.hi & 7) != 4 || !rd.in(h32.seg, h32.word, ((uint64_t)n + 1) / 2)) return fail(MHX_E_FORMAT, "%s: bad hash list", path);
@@ -293,8 +314,8 @@ int msh_read_file(const char *path, SketchSet &s)
                     for (uint32_t j = 0; j < n; ++j) r.hashes[j] = p32[j];
                 }
                 // the distance kernels merge ascending duplicate-free lists (what mash writes); anything else is a damaged file
-                for (size_t j = 1; j < r.hashes.size(); ++j)
-                    if (r.hashes[j] <= r.hashes[j - 1]) return fail(MHX_E_FORMAT, "%s: hash list of reference %u is not ascending", path, i);
+                // (a list left in the image as a view is checked by the caller)
+                if (!check_ascending(r.hashes.data(), r.hashes.size())) return fail(MHX_E_FORMAT, "%s: hash list of reference %u is not ascending", path, i);
                 if (ep > 6) {
                     Reader::Target c = rd.resolve(lst.seg, pp + 6);
                     if (c.ok && (c.hi & 7) == 4) {
