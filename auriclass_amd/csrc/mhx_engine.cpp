@@ -1323,6 +1323,7 @@ extern "C" int mhx_merge_shard_partials(const uint64_t *hashes, const uint32_t *
 
 // ---- batched distance ------------------------------------------------------------------
 extern "C" double mhx_last_dist_kernel_ms(void) { return g.last_dist_ms; }
+extern "C" int mhx_last_dist_fallback_blocks(void) { return g.last_dist_fallbacks; }
 
 // Persistent device staging of the host-pointer form (one buffer, grown on demand): six hipMalloc / hipFree pairs per
 // call cost more than the kernels of an AuriClass-sized comparison (1 query x 24 references).
@@ -1402,7 +1403,9 @@ static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq
     // outputs; the generic pair-per-workgroup kernel serves tiny batches and is the fallback of a block whose value
     // ranges are too uneven for the LDS table.  Nothing is read back between the blocks: every block has its own flag
     // word, all of them come back with ONE copy behind the last launch.
-    const bool fast = pairs >= 64 && getenv("MHX_DIST_GENERIC") == nullptr;
+    // (few pairs of LONG lists take it too -- AuriClass's own call, 1 query x 24 references at s = 50 000: 0.48 ms in the
+    // generic kernel, whose 24 workgroups each walk 100 000 elements)
+    const bool fast = (pairs >= 64 || (pairs >= 8 && pairs * (uint64_t)s >= 400000)) && getenv("MHX_DIST_GENERIC") == nullptr;
     uint32_t qbatch = nq;
     if (const char *e = getenv("MHX_DIST_QBATCH")) { const long v = atol(e); if (v > 0 && (uint64_t)v < nq) qbatch = (uint32_t)v; }
     const uint32_t nslices = (nr + 31) / 32, nbatches = (nq + qbatch - 1) / qbatch, nblocks = nslices * nbatches;
@@ -1441,7 +1444,7 @@ static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq
     };
     hipEventRecord(g.ev0, g.stream);
     hipError_t le = hipSuccess;
-    if (!fast) le = launch_dist_pairs(a, g.stream);
+    if (!fast) { le = launch_dist_pairs(a, g.stream); g.last_dist_fallbacks = -1; }
     for (uint32_t b = 0; fast && b < nblocks && le == hipSuccess; ++b) {
         w.params = d_params + 2 * b;
         le = launch_dist_ranges(block_args(b), w, g.stream);
@@ -1451,8 +1454,9 @@ static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq
         if (hipMemcpyAsync(flags.data(), d_params, flags.size() * 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
             hipStreamSynchronize(g.stream) != hipSuccess)
             return fail(MHX_E_HIP, "dist kernel failed");
+        g.last_dist_fallbacks = 0;
         for (uint32_t b = 0; b < nblocks && le == hipSuccess; ++b)
-            if (flags[2 * b + 1]) le = launch_dist_pairs(block_args(b), g.stream); // a value range overflowed the LDS table
+            if (flags[2 * b + 1]) { le = launch_dist_pairs(block_args(b), g.stream); ++g.last_dist_fallbacks; } // a value range overflowed the LDS table
     }
     hipEventRecord(g.ev1, g.stream);
     if (le != hipSuccess) return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le));

@@ -45,6 +45,7 @@ struct Engine {
     size_t dist_ws_cap = 0;
     uint8_t *dist_in = nullptr; // staging of a host-pointer distance batch (rows, lengths, outputs)
     size_t dist_in_cap = 0;
+    int last_dist_fallbacks = 0;
     uint8_t *dist_img = nullptr; // pinned image of the reference sketch file of mhx_dist_files
     size_t dist_img_cap = 0;
     // bulk file ingest: pinned staging ring + copy stream (allocated on first use, kept)

@@ -629,12 +629,14 @@ static int ensure_pinned_ring()
 static bool parallel_pread(int fd, uint8_t *dst, uint64_t off, size_t len, int nthreads)
 {
     JoinedThreads th;
+    if (nthreads < 1) nthreads = 1;
     std::vector<int> ok((size_t)nthreads, 1);
     const size_t per = ((len + (size_t)nthreads - 1) / (size_t)nthreads + 4095) & ~(size_t)4095;
     for (int t = 0; t < nthreads; ++t) {
         const size_t b = (size_t)t * per;
         if (b >= len) break;
         const size_t e = std::min(len, b + per);
+        const bool last = e == len; // the calling thread reads the last part itself (all of it when there is one part)
         auto part = [=, &ok]() {
             size_t done = b;
             while (done < e) {
@@ -643,7 +645,7 @@ static bool parallel_pread(int fd, uint8_t *dst, uint64_t off, size_t len, int n
                 done += (size_t)got;
             }
         };
-        if (!th.spawn(part)) part(); // no thread to be had: this one reads the part itself
+        if (last || !th.spawn(part)) part(); // (or no thread to be had)
     }
     th.join();
     for (int v : ok) if (!v) return false;
@@ -1292,6 +1294,11 @@ static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *s
     // five (file buffer, segment copies, hash vectors, padded matrix, pageable H2D staging): 5.6 -> 2 ms per call.
     SketchSet R, Q;
     std::vector<uint8_t> ref_heap;
+    static const bool timing = getenv("MHX_DIST_TIMING") != nullptr; // phase times of a call on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[mhx dist_files] %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     {
         struct stat sb;
         const int fd = open(ref_msh, O_RDONLY);
@@ -1313,8 +1320,10 @@ static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *s
         const bool ok = len == 0 || parallel_pread(fd, img, 0, len, len >= (4u << 20) ? std::min(8, ingest_thread_budget()) : 1);
         close(fd);
         if (!ok) return fail(MHX_E_IO, "cannot read %s", ref_msh);
+        lap("reference file read");
         rc = msh_parse_image(img, len, ref_msh, R, true);
         if (rc) return rc;
+        lap("parsed");
         // the distance kernels merge ascending duplicate-free lists (what mash writes); anything else is a damaged file
         std::vector<int> bad(R.refs.size(), 0);
         {
@@ -1330,9 +1339,11 @@ static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *s
         }
         for (size_t i = 0; i < bad.size(); ++i)
             if (bad[i]) return fail(MHX_E_FORMAT, "%s: hash list of reference %zu is not ascending", ref_msh, i);
+        lap("order checked");
     }
     rc = msh_read_file(qry_msh, Q);
     if (rc) return rc;
+    lap("query read");
     if (R.kmer_size != Q.kmer_size)
         return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different k-mer sizes (%u and %u)", Q.kmer_size, R.kmer_size);
     if (R.hash_seed != Q.hash_seed) return fail(MHX_E_MISMATCH, "ERROR: The query and reference sketches have different hash seeds");
@@ -1349,6 +1360,7 @@ static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *s
         std::vector<double> dist((size_t)nq * nr);
         rc = dist_batch_rows(qrows.data(), ql.data(), nq, rrows.data(), rl.data(), nr, k, s, common.data(), denom.data(), dist.data());
         if (rc) return rc;
+        lap("distances back");
         for (uint32_t qi = 0; qi < nq; ++qi)
             for (uint32_t ri = 0; ri < nr; ++ri) {
                 const size_t p = (size_t)qi * nr + ri;

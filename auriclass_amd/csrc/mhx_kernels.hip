@@ -1049,6 +1049,34 @@ __device__ __forceinline__ uint32_t wave_sum_bytes(uint32_t v)
     return v;
 }
 
+// One reference hash into the range's LDS table: key -> bit mask of the references that hold it.  `ndistinct` counts the
+// keys (slots claimed).  Whether a range fits is decided by THAT number, not by the sum of the references' slice sizes:
+// references of one clade share most of their hashes (AuriClass's 24 C. auris references do), so 24 slices of 65 hashes
+// are 70 keys, not 1560 -- with the sum as the test every such reference set fell back to the generic kernel (0.48 ms
+// instead of 0.05 for AuriClass's own 1 x 24 comparison, 62 ms instead of 0.4 for 1024 queries).  The probe sequence is
+// bounded by the table size, so a table that does fill up (non-uniform values) ends the build instead of hanging it; the
+// caller checks `ndistinct` against kDistTableLimit behind the barrier and gives the range up.
+constexpr uint32_t kDistTableLimit = (kDistTableSlots * 3) / 4;
+// returns the number of keys this call added (0 or 1; kDistTableSlots when the table had no room at all): the callers sum
+// it per thread and add the wave totals to the shared count once, behind the build (dist_table_count)
+__device__ __forceinline__ uint32_t dist_table_insert(unsigned long long *keys, uint32_t *masks, uint64_t v, uint32_t r)
+{
+    uint32_t sl = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1);
+#pragma nounroll
+    for (int probe = 0; probe < kDistTableSlots; ++probe) {
+        const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
+        if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); return prev == kEmptyKey ? 1u : 0u; }
+        sl = (sl + 1) & (kDistTableSlots - 1);
+    }
+    return (uint32_t)kDistTableSlots;
+}
+__device__ __forceinline__ void dist_table_count(uint32_t *ndistinct, uint32_t mine)
+{ // all lanes of the wave call this
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(ndistinct, mine);
+}
+
 __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistWork w)
 {
     __shared__ unsigned long long keys[kDistTableSlots];
@@ -1059,14 +1087,8 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
     const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < kDistTableSlots; i += 256) { keys[i] = kEmptyKey; masks[i] = 0; }
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (uint32_t r = 0; r < a.nr; ++r) tot += w.offs_r[r * per + p + 1] - w.offs_r[r * per + p];
-        too_big = tot > (kDistTableSlots * 3) / 4;
-        if (too_big) atomicOr(&w.params[1], 1u);
-    }
+    if (tid == 0) too_big = 0; // number of distinct keys in the table
     __syncthreads();
-    if (too_big) return; // non-uniform input: the host reruns the generic kernel
     auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
     // build: wave w inserts references w, w+4, ...; a reference's slice of this range is a
     // few dozen hashes, so all slices of the wave are loaded first, then inserted
@@ -1074,6 +1096,7 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
         constexpr int G = 8; // 32 references / 4 waves
         uint64_t x[G];
         bool have[G];
+        uint32_t added = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const uint32_t r = wave + 4 * g;
@@ -1090,16 +1113,16 @@ __global__ __launch_bounds__(256) void dist_range_kernel(const DistArgs a, DistW
             const uint32_t b = w.offs_r[r * per + p], e = w.offs_r[r * per + p + 1];
             for (uint32_t i = b + lane; i < e; i += 64) {
                 const uint64_t v = (i == b + lane && have[g]) ? x[g] : a.r[(uint64_t)r * a.stride + i];
-                uint32_t sl = slot_of(v);
-                for (;;) {
-                    const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
-                    if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
-                    sl = (sl + 1) & (kDistTableSlots - 1);
-                }
+                added += dist_table_insert(keys, masks, v, r);
             }
         }
+        dist_table_count(&too_big, added);
     }
     __syncthreads();
+    if (too_big > kDistTableLimit) { // non-uniform input: the host reruns the generic kernel (uniform exit: the count is shared)
+        if (tid == 0) atomicOr(&w.params[1], 1u);
+        return;
+    }
     // probe: wave w takes queries q0+w, q0+w+4, ... of this block's chunk, 8 at a time so that
     // eight global loads are in flight per lane; each query element is looked up once and its reference mask (one bit
     // per reference) is spread into byte counters, four references to a word; one DPP reduction per word and query
@@ -1173,30 +1196,19 @@ __global__ __launch_bounds__(kLaneBlock) void dist_range_lane_kernel(const DistA
 {
     __shared__ unsigned long long keys[kDistTableSlots];
     __shared__ uint32_t masks[kDistTableSlots];
+    __shared__ uint32_t ndistinct; // keys in the table
     const uint32_t p = (blockIdx.x & 7u) * (kDistRanges / 8) + (blockIdx.x >> 3), per = kDistRanges + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // where range p begins and ends in every reference: lane r of EVERY wave holds reference r's pair (nr <= 32), so each
-    // wave knows the table load by itself and all reference loads of the build are issued together -- two HBM round trips
-    // for the whole build instead of two per reference and wave
+    // where range p begins and ends in every reference: lane r of EVERY wave holds reference r's pair (nr <= 32), so all
+    // reference loads of the build are issued together -- two HBM round trips for the whole build instead of two per
+    // reference and wave
     uint32_t rb = 0, re = 0;
     if ((uint32_t)lane < a.nr) { rb = w.offs_r[lane * per + p]; re = w.offs_r[lane * per + p + 1]; }
     for (int i = tid; i < kDistTableSlots; i += kLaneBlock) { keys[i] = kEmptyKey; masks[i] = 0; }
-    uint32_t tot = re - rb;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
-    if (tot > (kDistTableSlots * 3) / 4) { // the same in every wave: a uniform exit
-        if (tid == 0) atomicOr(&w.params[1], 1u);
-        return;
-    }
+    if (tid == 0) ndistinct = 0;
     auto slot_of = [](uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
-    auto insert = [&](uint64_t v, uint32_t r) {
-        uint32_t sl = slot_of(v);
-        for (;;) {
-            const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
-            if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << r); break; }
-            sl = (sl + 1) & (kDistTableSlots - 1);
-        }
-    };
+    uint32_t added = 0;
+    auto insert = [&](uint64_t v, uint32_t r) { added += dist_table_insert(keys, masks, v, r); };
     constexpr int kWaves = kLaneBlock / 64, kPerWave = (32 + kWaves - 1) / kWaves;
     uint64_t rv[kPerWave];
     uint32_t have = 0;
@@ -1215,7 +1227,12 @@ __global__ __launch_bounds__(kLaneBlock) void dist_range_lane_kernel(const DistA
         const uint32_t b = __shfl(rb, (int)r), e = __shfl(re, (int)r);
         for (uint32_t i = b + 64u + lane; i < e; i += 64) insert(a.r[(uint64_t)r * a.stride + i], r);
     }
+    dist_table_count(&ndistinct, added);
     __syncthreads();
+    if (ndistinct > kDistTableLimit) { // non-uniform input: the host reruns the generic kernel (uniform exit: the count is shared)
+        if (tid == 0) atomicOr(&w.params[1], 1u);
+        return;
+    }
     const uint32_t q = blockIdx.y * kLaneBlock + tid;
     if (q >= a.nq) return;
     const uint32_t nwords = (a.nr + 3) / 4;
@@ -1354,31 +1371,26 @@ __global__ __launch_bounds__(256) void dist_walk_kernel(const DistArgs a, DistWo
     uint4 x[kLineElems / 2] = {};
     uint32_t loaded = 0xFFFFFFFFu; // first element of the line held in x
     auto slot_of = [](uint64_t v) { return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 40) & (kDistTableSlots - 1); };
+#pragma nounroll
     for (uint32_t r = 0; r < kDistWalk; ++r) {
         const uint32_t p = g * kDistWalk + r;
         for (int s2 = tid; s2 < kDistTableSlots; s2 += 256) { keys[s2] = kEmptyKey; masks[s2] = 0; }
-        if (tid == 0) {
-            uint32_t tot = 0;
-            for (uint32_t rr = 0; rr < a.nr; ++rr) tot += w.offs_r[rr * per + p + 1] - w.offs_r[rr * per + p];
-            too_big = tot > (kDistTableSlots * 3) / 4;
-            if (too_big) atomicOr(&w.params[1], 1u);
-        }
+        if (tid == 0) too_big = 0; // number of distinct keys in the table
         __syncthreads();
-        if (too_big) return; // non-uniform input: the host reruns the generic kernel (uniform exit: too_big is shared)
+        uint32_t added = 0;
         for (uint32_t rr = wave; rr < a.nr; rr += 4) { // build: wave w inserts references w, w + 4, ...
             const uint32_t b = w.offs_r[rr * per + p], e = w.offs_r[rr * per + p + 1];
             for (uint32_t j = b + lane; j < e; j += 64) {
-                const uint64_t v = a.r[(uint64_t)rr * a.stride + j];
-                uint32_t sl = slot_of(v);
-                for (;;) {
-                    const unsigned long long prev = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)v);
-                    if (prev == kEmptyKey || prev == v) { atomicOr(&masks[sl], 1u << rr); break; }
-                    sl = (sl + 1) & (kDistTableSlots - 1);
-                }
+                added += dist_table_insert(keys, masks, a.r[(uint64_t)rr * a.stride + j], rr);
             }
         }
+        dist_table_count(&too_big, added);
         __syncthreads();
-        if (live) {
+        // non-uniform input (the table overflowed): the host reruns the generic kernel; this range is skipped.  (No return
+        // here: an exit between the build and the walk makes hipcc keep 112 instead of 78 VGPRs, four waves per SIMD
+        // instead of six, and the walk 15 % slower.)
+        if (tid == 0 && too_big > kDistTableLimit) atomicOr(&w.params[1], 1u);
+        if (live && too_big <= kDistTableLimit) {
             uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const uint32_t begin = i;
             bool more = true; // this lane's walk through range p

@@ -105,6 +105,7 @@ def load() -> ctypes.CDLL:
     L.mhx_dist_batch.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32,
                                  c.c_int, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
     L.mhx_last_dist_kernel_ms.restype = c.c_double
+    L.mhx_last_dist_fallback_blocks.restype = c.c_int
     L.mhx_p_value.argtypes = [c.c_uint64, c.c_uint64, c.c_uint64, c.c_int, c.c_uint64]
     L.mhx_p_value.restype = c.c_double
     L.mhx_msh_write.argtypes = [c.c_char_p, c.c_int, c.c_uint32, c.c_uint32, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
@@ -155,11 +156,17 @@ def stream_handle() -> int:
     return load().mhx_stream() or 0
 
 
-def _text_call(fn, *args) -> str:
+def _text_call(fn, *args, guess: int = 1 << 16) -> str:
+    """The C ABI's two-call text pattern (size, then fill) with the first call already carrying a buffer: a text that
+    fits it -- the 24 rows of an AuriClass `mash dist`, the bounds table -- costs ONE call (the library does the whole
+    work in either call); a longer one reports its size (MHX_E_CAPACITY, `need`) and is fetched by a second call."""
     need = ctypes.c_size_t(0)
-    _check(fn(*args, None, 0, ctypes.byref(need)))
-    buf = ctypes.create_string_buffer(need.value)
-    _check(fn(*args, buf, need.value, ctypes.byref(need)))
+    buf = ctypes.create_string_buffer(guess)
+    rc = fn(*args, buf, guess, ctypes.byref(need))
+    if rc == MHX_E_CAPACITY and need.value > guess:
+        buf = ctypes.create_string_buffer(need.value)
+        rc = fn(*args, buf, need.value, ctypes.byref(need))
+    _check(rc)
     return buf.value.decode("utf-8", "surrogateescape")   # names inside a .msh are arbitrary bytes
 
 

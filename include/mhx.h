@@ -191,6 +191,9 @@ int mhx_dist_batch(const uint64_t *q, const uint32_t *q_len, uint32_t nq, const 
                    const uint32_t *r_len, uint32_t nr, uint32_t stride, int k, uint32_t s,
                    uint32_t *common, uint32_t *denom, double *dist, int device_ptrs);
 double mhx_last_dist_kernel_ms(void);
+/* diagnostics of the last mhx_dist_batch / mhx_dist_files call: -1 = the generic pair kernel did all the work (tiny batch),
+ * else the number of (query batch, reference slice) blocks the all-vs-refs fast path gave up to it (0 for uniform hashes) */
+int mhx_last_dist_fallback_blocks(void);
 
 /* scalar pieces of the dist row (host): mash pValue() */
 double mhx_p_value(uint64_t common, uint64_t len_ref, uint64_t len_qry, int k, uint64_t denom);

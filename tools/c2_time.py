@@ -45,6 +45,6 @@ for k, s in ((21, 1000), (27, 50000)):
     print(f"24 x 12 Mb refs k={k} s={s}: sketch {m:.1f} ms median, {lo:.1f} min ({m / 24:.2f} ms per file)", flush=True)
     engine.sketch_files([fa], k, s, a_msh)
     m, lo = med(lambda: engine.dist_files(r_msh, a_msh), 9)
-    print(f"dist, 1 query x 24 refs k={k} s={s}: {m:.2f} ms median, {lo:.2f} min", flush=True)
+    print(f"dist, 1 query x 24 refs k={k} s={s}: {m:.2f} ms median, {lo:.2f} min (kernels of the last call: {engine.load().mhx_last_dist_kernel_ms():.3f} ms)", flush=True)
 for p in refs + [fa, fagz]:
     os.unlink(p)
