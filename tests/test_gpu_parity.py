@@ -1334,3 +1334,34 @@ def test_dist_references_of_one_clade_stay_on_the_fast_path(nq):
             c, d, dd = mo.compare(r, qrys[qi], s, 27)
             assert (common[qi, ri], denom[qi, ri]) == (c, d), (qi, ri)
             assert dist[qi, ri] == dd
+
+
+def test_fastq4_with_empty_reads_and_illumina_style_headers():
+    """Reads trimmed to nothing (`@h / (empty) / + / (empty)`, which kseq reads as a record without bases) among short and
+    long ones, headers in Illumina's style (they hold `:`, blanks, `+` and `@`), qualities that begin with `@` or `+`:
+    the tile-local line-phase search and the per-record layout check must neither trip over the empty lines nor take a
+    quality line for a header."""
+    import torch
+
+    rng = np.random.default_rng(314)
+    lens = rng.choice([0, 0, 1, 20, 21, 22, 75, 151], size=6000)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(L))) for L in lens]
+    quals = np.frombuffer(b"@+FF:,#", np.uint8)
+    rec = []
+    for i, r in enumerate(reads):
+        q = bytes(rng.choice(quals, size=len(r)))
+        hdr = b"A00%d:45:HXX+DSXX:1:1101:%d:1000 1:N:0:ACGT+TG@A" % (i % 7, 1000 + i)
+        rec.append(b"@" + hdr + b"\n" + r + b"\n+" + (hdr if i % 3 == 0 else b"") + b"\n" + q + b"\n")   # old style: the `+` line repeats the name
+    data = b"".join(rec)
+    dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    for k, s, m in ((21, 1000, 1), (21, 500, 2)):
+        sk = engine.Sketcher(k, s, m, expected_bytes=len(data))
+        sk.push_device(dev.data_ptr(), len(data), engine.FMT_FASTQ4)
+        got, cnt = sk.finish()
+        st = sk.stats()
+        n_rec = sk.record_count()
+        sk.close()
+        want, wc = mo.bruteforce_sketch(reads, k, s, m)
+        assert st["flags"] == 0
+        assert np.array_equal(got, want) and np.array_equal(cnt, wc)
+        assert n_rec == sum(1 for r in reads if len(r) >= k)
