@@ -334,8 +334,8 @@ def _pad_rows(lists, stride):
     return M, np.array([len(v) for v in lists], np.uint32)
 
 
-def _check_all_pairs(qrys, refs, k, s):
-    stride = max(max(map(len, refs)), max(map(len, qrys)), 1)
+def _check_all_pairs(qrys, refs, k, s, pad=1):
+    stride = (max(max(map(len, refs)), max(map(len, qrys)), 1) + pad - 1) // pad * pad
     Q, ql = _pad_rows(qrys, stride)
     R, rl = _pad_rows(refs, stride)
     common, denom, dist = engine.dist_batch(Q, ql, R, rl, k, s)
@@ -757,15 +757,22 @@ def test_randomised_file_level_reads_mode(tmp_path, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds(6))
-def test_randomised_dist_batches(seed):
+def test_randomised_dist_batches(seed, monkeypatch):
     """Random batch shapes for mash's compareSketches on the device: 1..40 references (both sides of the
-    32-reference fast path), ragged list lengths, shared fractions from 0 to 1, tiny and full sketches."""
+    32-reference fast path), ragged list lengths, shared fractions from 0 to 1, tiny and full sketches; one batch in
+    three is large enough for the one-query-per-lane form, half of those take the walk form; rows padded to nothing, to
+    whole 64-byte or to whole 128-byte lines (the three load paths of the lane form)."""
     rng = np.random.default_rng(8200 + seed)
     s = int(rng.choice([64, 1000, 5000]))
     k = int(rng.choice([16, 21, 27]))
     hi = 2 ** 32 if k <= 16 else 2 ** 64
     nr = int(rng.integers(1, 41))
     nq = int(rng.integers(1, 90))
+    if rng.random() < 0.33:
+        nq = int(rng.integers(128, 260))
+        if rng.random() < 0.5:
+            monkeypatch.setenv("MHX_DIST_WALK_MIN", "128")
+    pad = int(rng.choice([1, 8, 16]))
     base = _sketch_like(rng, 3 * s, hi)
     refs = [np.sort(rng.choice(base, size=int(rng.integers(1, s + 1)), replace=False)) for _ in range(nr)]
     qrys = []
@@ -776,7 +783,7 @@ def test_randomised_dist_batches(seed):
         fresh = _sketch_like(rng, int(rng.integers(0, s // 2 + 1)), hi)
         q = np.unique(np.concatenate([keep, fresh]))[: s]
         qrys.append(q)
-    _check_all_pairs(qrys, refs, k, s)
+    _check_all_pairs(qrys, refs, k, s, pad)
 
 
 @pytest.mark.parametrize("seed", _seeds(5))
