@@ -1372,3 +1372,34 @@ def test_fastq4_with_empty_reads_and_illumina_style_headers():
         assert st["flags"] == 0
         assert np.array_equal(got, want) and np.array_equal(cnt, wc)
         assert n_rec == sum(1 for r in reads if len(r) >= k)
+
+
+@pytest.mark.parametrize("s", [1000, 50000])
+def test_dist_files_on_a_large_reference_file_and_a_damaged_one(tmp_path, s):
+    """`mash dist REF QUERY` at file level with a reference sketch file of 24 clade-like references: at s = 50 000 (9.6 MB)
+    the file goes through the pinned image / in-place parse / row-by-row copy path, at s = 1000 through the heap; the text
+    must be the oracle's.  The same file with two neighbouring hashes of one reference swapped (an order the merge
+    kernels cannot work on) must be refused, by the parallel order check of the large file and by the small one's."""
+    rng = np.random.default_rng(5 + s)
+    base = _sketch_like(rng, s)
+    refs = []
+    for j in range(24):
+        keep = rng.random(len(base)) >= 0.001 * (j + 1)
+        h = np.unique(np.concatenate([base[keep], _sketch_like(rng, int((~keep).sum()))]))
+        refs.append(mo.Reference("ref%d.fa" % j, "clade %d" % (j % 5), 12_000_000 + j, h))
+    q = np.unique(np.concatenate([refs[7].hashes[::2], _sketch_like(rng, s // 2)]))[:s]
+    R = mo.SketchFile(kmer_size=27, sketch_size=s, references=refs)
+    Q = mo.SketchFile(kmer_size=27, sketch_size=s, references=[mo.Reference("sample.fa", "query", 12_300_000, q)])
+    (tmp_path / "r.msh").write_bytes(mo.msh_bytes(R))
+    (tmp_path / "q.msh").write_bytes(mo.msh_bytes(Q))
+    for _ in range(2):   # the second call reuses the pinned image
+        assert engine.dist_files(tmp_path / "r.msh", tmp_path / "q.msh") == mo.dist_text(R, Q)
+    assert engine.load().mhx_last_dist_fallback_blocks() <= 0   # fast path without a fallback (s = 50 000) or the tiny-batch kernel
+    bad = refs[13].hashes.copy()
+    bad[[len(bad) // 2, len(bad) // 2 + 1]] = bad[[len(bad) // 2 + 1, len(bad) // 2]]
+    damaged = list(refs)   # (R holds `refs` itself)
+    damaged[13] = mo.Reference(refs[13].name, refs[13].comment, refs[13].length, bad)
+    (tmp_path / "bad.msh").write_bytes(mo.msh_bytes(mo.SketchFile(kmer_size=27, sketch_size=s, references=damaged)))
+    with pytest.raises(engine.EngineError, match="not ascending"):
+        engine.dist_files(tmp_path / "bad.msh", tmp_path / "q.msh")
+    assert engine.dist_files(tmp_path / "r.msh", tmp_path / "q.msh") == mo.dist_text(R, Q)   # and the engine is fine afterwards
