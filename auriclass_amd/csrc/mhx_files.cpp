@@ -1305,7 +1305,7 @@ static int mhx_dist_files_impl(const char *ref_msh, const char *qry_msh, char *s
         if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { if (fd >= 0) close(fd); return fail(MHX_E_IO, "cannot open sketch %s", ref_msh); }
         const size_t len = (size_t)sb.st_size;
         uint8_t *img = nullptr;
-        if (len >= (1u << 20) && len <= (1ull << 32)) { // a pinned block of its own, kept between calls (MHX_DIST_PAGEABLE=1: the heap, for comparison)
+        if (len >= (1u << 20) && len <= (256u << 20)) { // a pinned block of its own, kept between calls (larger files, or MHX_DIST_PAGEABLE=1: the heap)
             if (g.dist_img_cap < len && !getenv("MHX_DIST_PAGEABLE")) {
                 if (g.dist_img) hipHostFree(g.dist_img);
                 g.dist_img = nullptr;
