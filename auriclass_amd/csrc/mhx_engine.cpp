@@ -1411,10 +1411,10 @@ static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq
     const uint32_t nslices = (nr + 31) / 32, nbatches = (nq + qbatch - 1) / qbatch, nblocks = nslices * nbatches;
     DistWork w{};
     uint32_t *d_params = nullptr;
+    constexpr uint32_t kBlockGroup = 4096; // blocks whose flag words come back together (a reference set of 131 072 sketches per group)
     if (fast) {
-        if (nblocks > 4096) return fail(MHX_E_ARG, "too many (query batch, reference slice) blocks in one call");
         size_t oq, orr, oc, op;
-        const size_t need = dist_work_bytes(qbatch, nr < 32 ? nr : 32, &oq, &orr, &oc, &op) + (size_t)nblocks * 8;
+        const size_t need = dist_work_bytes(qbatch, nr < 32 ? nr : 32, &oq, &orr, &oc, &op) + (size_t)std::min(nblocks, kBlockGroup) * 8;
         if (g.dist_ws_cap < need) {
             HIPCHK(hipStreamSynchronize(g.stream));
             hipFree(g.dist_ws);
@@ -1445,18 +1445,20 @@ static int dist_batch_core(const uint64_t *q, const uint32_t *q_len, uint32_t nq
     hipEventRecord(g.ev0, g.stream);
     hipError_t le = hipSuccess;
     if (!fast) { le = launch_dist_pairs(a, g.stream); g.last_dist_fallbacks = -1; }
-    for (uint32_t b = 0; fast && b < nblocks && le == hipSuccess; ++b) {
-        w.params = d_params + 2 * b;
-        le = launch_dist_ranges(block_args(b), w, g.stream);
-    }
-    if (fast && le == hipSuccess) {
-        std::vector<uint32_t> flags((size_t)nblocks * 2);
+    if (fast) g.last_dist_fallbacks = 0;
+    for (uint32_t b0 = 0; fast && b0 < nblocks && le == hipSuccess; b0 += kBlockGroup) {
+        const uint32_t b1 = std::min(nblocks, b0 + kBlockGroup);
+        for (uint32_t b = b0; b < b1 && le == hipSuccess; ++b) {
+            w.params = d_params + 2 * (b - b0);
+            le = launch_dist_ranges(block_args(b), w, g.stream);
+        }
+        if (le != hipSuccess) break;
+        std::vector<uint32_t> flags((size_t)(b1 - b0) * 2);
         if (hipMemcpyAsync(flags.data(), d_params, flags.size() * 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
             hipStreamSynchronize(g.stream) != hipSuccess)
             return fail(MHX_E_HIP, "dist kernel failed");
-        g.last_dist_fallbacks = 0;
-        for (uint32_t b = 0; b < nblocks && le == hipSuccess; ++b)
-            if (flags[2 * b + 1]) { le = launch_dist_pairs(block_args(b), g.stream); ++g.last_dist_fallbacks; } // a value range overflowed the LDS table
+        for (uint32_t b = b0; b < b1 && le == hipSuccess; ++b)
+            if (flags[2 * (b - b0) + 1]) { le = launch_dist_pairs(block_args(b), g.stream); ++g.last_dist_fallbacks; } // a value range overflowed the LDS table
     }
     hipEventRecord(g.ev1, g.stream);
     if (le != hipSuccess) return fail(MHX_E_HIP, "dist kernel launch failed: %s", hipGetErrorString(le));

@@ -1403,3 +1403,23 @@ def test_dist_files_on_a_large_reference_file_and_a_damaged_one(tmp_path, s):
     with pytest.raises(engine.EngineError, match="not ascending"):
         engine.dist_files(tmp_path / "bad.msh", tmp_path / "q.msh")
     assert engine.dist_files(tmp_path / "r.msh", tmp_path / "q.msh") == mo.dist_text(R, Q)   # and the engine is fine afterwards
+
+
+def test_dist_reference_sets_beyond_one_group_of_blocks():
+    """One query against 135 000 tiny reference sketches: 4219 slices of 32 references -- more than the 4096 blocks whose
+    flag words come back in one copy (such a call used to be refused)."""
+    rng = np.random.default_rng(99)
+    s, nr = 12, 135_000
+    pool = _sketch_like(rng, 400)
+    R = np.zeros((nr, 16), np.uint64)
+    rl = rng.integers(0, s + 1, size=nr).astype(np.uint32)
+    for i in range(nr):
+        R[i, :rl[i]] = np.sort(rng.choice(pool, size=int(rl[i]), replace=False))
+    q = np.sort(rng.choice(pool, size=s, replace=False))
+    Q = np.zeros((1, 16), np.uint64)
+    Q[0, :s] = q
+    common, denom, dist = engine.dist_batch(Q, np.array([s], np.uint32), R, rl, 21, s)
+    for i in list(range(0, nr, 997)) + [nr - 1, 131_071, 131_072, 131_073]:
+        c, d, dd = mo.compare(R[i, :rl[i]], q, s, 21)
+        assert (common[0, i], denom[0, i]) == (c, d), i
+        assert dist[0, i] == dd
