@@ -425,3 +425,44 @@ def test_sharded_distances_on_the_gpu_equal_the_oracle(tmp_path, world, nq):
         z = np.load(tmp_path / f"d{r}.npz")
         assert np.array_equal(z["c"], wc) and np.array_equal(z["d"], wd), f"rank {r}"
         assert np.allclose(z["x"], wx, rtol=1e-12, atol=0), f"rank {r}"   # device log vs libm: a few ulp
+
+
+def _sparse_worker(rank, world, port, k, s, m, n_reads, form, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auriclass_amd import engine
+
+    engine.init(0)
+    fq = _input(n_reads)
+    rb = synth.record_bytes(READ_LEN)
+    lo, hi = multigpu.shard_bounds(n_reads, world, rank)
+    sk = engine.Sketcher(k, s, m, expected_bytes=max(1, (hi - lo) * rb))
+    if hi > lo:
+        shard = torch.from_numpy(fq[lo * rb:hi * rb]).to("cuda:0")
+        torch.cuda.synchronize()
+        sk.push_device(shard.data_ptr(), shard.numel(), engine.FMT_FASTQ4)
+        sk.sync()
+    got_h, got_c = _exchange(sk, form, k, s, m)
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), got_h)
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), got_c)
+    sk.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form", ["device", "device-cuda", "host"])
+@pytest.mark.parametrize("m", [1, 2])
+def test_fewer_records_than_ranks(tmp_path, form, m):
+    """Two reads over three ranks: one rank's sketcher never sees a byte (empty partial, threshold still the largest hash
+    value); the merged sketch -- shorter than s, which is exact when no rank has ever rejected a hash -- is the oracle's
+    on every rank."""
+    from oracle import mash_oracle as mo
+
+    world, k, s, n_reads = 3, 21, 500, 2
+    mp.spawn(_sparse_worker, args=(world, _free_port(), k, s, m, n_reads, form, str(tmp_path)), nprocs=world, join=True)
+    want, wc = mo.bruteforce_sketch(_seqs(_input(n_reads).tobytes()), k, s, m)
+    assert len(want) < s
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), wc), f"rank {r}"

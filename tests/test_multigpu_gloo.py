@@ -82,6 +82,25 @@ def test_exchange_and_merge_equals_single_sketch(tmp_path, world, k, s, m):
         assert cnt.min() >= m
 
 
+@pytest.mark.parametrize("world,n_reads,m", [(3, 2, 1), (3, 2, 2), (2, 1, 1)])
+def test_exchange_with_an_empty_shard_and_fewer_kmers_than_the_sketch_holds(tmp_path, world, n_reads, m):
+    """Fewer records than ranks: some rank holds nothing (its partial is empty, its threshold still the largest hash
+    value); the union has fewer than s k-mers, which is exact as long as no rank has ever rejected a hash."""
+    from oracle import mash_oracle as mo
+
+    engine.build()
+    k, s = 21, 500
+    mp.spawn(_worker, args=(world, _free_port(), k, s, m, n_reads, str(tmp_path)), nprocs=world, join=True)
+    genome = synth.make_genome(30_000, seed=9)
+    fq = synth.make_fastq(genome, n_reads, 100, seed=10, device="cpu").numpy().tobytes()
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(fq)
+    want, _ = ref.finish()
+    assert len(want) < s
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
+
+
 class _FakeSketcher:
     """Stands where engine.Sketcher stands in multigpu.sharded_sketch: the shard's exact (hash, count) table with a
     CAPPED admission threshold, the cap widening with the budget scale as the engine's does."""
