@@ -108,12 +108,17 @@ int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out)
         }
     }
     for (;;) {
-        const size_t r = inf.inflate(out.data() + n, out.size() - slack - n, out.data());
+        // (the decoder may run up to kOvershoot bytes past the room it is given -- `slack` is there for that --, so `n` can
+        // end beyond size - slack: the room left is computed without wrapping.  It did wrap: a file of several members
+        // whose last one announces less than the whole -- `cat a.gz b.gz` -- spun here for ever, asking for 2^64 bytes)
+        const size_t room = out.size() - slack > n ? out.size() - slack - n : 0;
+        if (room < (1u << 16)) { out.resize(out.size() * 2); continue; } // more members than the hint covered
+        const size_t r = inf.inflate(out.data() + n, room, out.data());
         if (r == (size_t)-1) return read_all_zlib(path, out); // zlib has the last word on a stream this decoder refuses
         n += r;
         if (inf.done()) break;
-        if (out.size() - slack - n < (1u << 16)) out.resize(out.size() * 2); // more members than the hint covered
     }
+    if (n > out.size()) return fail(MHX_E_INTERNAL, "inflate wrote past its buffer"); // (cannot happen: room + kOvershoot < slack + room)
     out.resize(n);
     return MHX_OK;
 }

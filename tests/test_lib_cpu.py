@@ -392,3 +392,26 @@ def test_fasta_reader_takes_bgzf(tmp_path):
     p.write_bytes(bytes(bad))
     with pytest.raises(engine.EngineError):
         engine.fasta_total_bases(p)
+
+
+@pytest.mark.timeout(120)
+def test_whole_file_reader_on_concatenated_members_longer_than_the_last_one_announces(tmp_path):
+    """`cat a.gz b.gz c.gz` through the whole-file reader (FASTA inputs, and FASTQ the streaming ingest declines): the
+    output buffer is sized from the LAST member's length field, so the members before it make it grow while the
+    sequential decoder is at work -- whose last call may run a few bytes past the room it was given.  The room left
+    was computed as an unsigned difference and wrapped: the reader then spun for ever (found by running the GPU suite with
+    the streaming ingest switched off).  Large first member: the multi-threaded decoder takes it, the rest goes to the
+    sequential one; small members: all sequential; both must deliver every base."""
+    import gzip
+
+    rng = np.random.default_rng(3)
+
+    def fasta(n_rec, length, tag):
+        return b"".join(b">%s%d\n" % (tag, i) + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=length)) + b"\n" for i in range(n_rec))
+
+    for sizes in ((400, 1, 700), (3, 40, 5), (900, 2)):
+        parts = [fasta(n, 9000, b"r%d_" % j) for j, n in enumerate(sizes)]
+        p = tmp_path / ("m%d.fa.gz" % sizes[0])
+        p.write_bytes(b"".join(gzip.compress(x, compresslevel=4) for x in parts))
+        assert engine.fasta_total_bases(p) == 9000 * sum(sizes)
+        assert engine.sniff_fasta(p) and not engine.sniff_fastq(p)
