@@ -439,7 +439,7 @@ def test_dist_non_uniform_values_fall_back_to_the_generic_kernel(monkeypatch, fo
             for ri, r in enumerate(refs):
                 c, d, dd = mo.compare(r, qrys[qi], 3000, 21)
                 assert (common[qi, ri], denom[qi, ri]) == (c, d), (form, qi, ri)
-    assert engine.load().mhx_last_dist_fallback_blocks() == 1
+    assert engine.load().mhx_last_dist_fallback_blocks() >= 1   # (one block; more when MHX_DIST_QBATCH cuts the queries into batches)
 
 
 def test_dist_more_than_32_refs_and_k16_32bit_hashes():
