@@ -1423,3 +1423,30 @@ def test_dist_reference_sets_beyond_one_group_of_blocks():
         c, d, dd = mo.compare(R[i, :rl[i]], q, s, 21)
         assert (common[0, i], denom[0, i]) == (c, d), i
         assert dist[0, i] == dd
+
+
+@pytest.mark.parametrize("seed", _seeds(4))
+def test_randomised_concatenated_gzip_members(tmp_path, monkeypatch, seed):
+    """`cat a.gz b.gz ...`: 1 .. 6 members of a few records to a few MB each, any compression level, cut at arbitrary
+    record boundaries or in the middle of a record; through the streaming ingest and (every other seed) through the
+    whole-file reader that takes over when the ingest declines; the member that announces its length last is often not
+    the longest (the whole-file reader sizes its buffer from it)."""
+    import gzip
+
+    rng = np.random.default_rng(9900 + seed)
+    if seed % 2:
+        monkeypatch.setenv("MHX_NO_STREAMING", "1")
+    k, s, m = int(rng.choice([21, 27])), int(rng.choice([500, 5000])), int(rng.choice([1, 2]))
+    genome = synth.make_genome(int(rng.integers(40_000, 200_000)), seed=500 + seed)
+    n_members = int(rng.integers(1, 7))
+    reads = [int(rng.choice([1, 3, 50, 4000, 20_000, 60_000])) for _ in range(n_members)]
+    data = b"".join(synth.make_fastq(genome, n, 100, seed=1000 * seed + i, device="cpu", first_index=i * 100_000).numpy().tobytes() for i, n in enumerate(reads))
+    cuts = sorted(set([0, len(data)] + [int(rng.integers(0, len(data))) for _ in range(n_members - 1)]))   # members need not end with a record
+    p = tmp_path / "cat.fq.gz"
+    p.write_bytes(b"".join(gzip.compress(data[a:b], compresslevel=int(rng.integers(1, 10))) for a, b in zip(cuts, cuts[1:])))
+    engine.sketch_files([p], k, s, tmp_path / "o.msh", reads=True, min_mult=m)
+    ref = mo.Sketcher(k, s, m)
+    ref.add_fastx(data)
+    got = mo.read_msh(tmp_path / "o.msh").references[0]
+    assert np.array_equal(got.hashes, ref.finish()[0]), (seed, reads, cuts)
+    assert got.comment == ref.comment()
