@@ -1450,3 +1450,47 @@ def test_randomised_concatenated_gzip_members(tmp_path, monkeypatch, seed):
     got = mo.read_msh(tmp_path / "o.msh").references[0]
     assert np.array_equal(got.hashes, ref.finish()[0]), (seed, reads, cuts)
     assert got.comment == ref.comment()
+
+
+@pytest.mark.parametrize("which", ["first", "second", "both", "truncated", "missing"])
+def test_one_bad_file_of_a_pair_ends_the_call_not_the_process(tmp_path, which):
+    """Two `.fq.gz` files decoded side by side (AuriClass's paired reads), each several ingest chunks long: when one of
+    them is damaged in the middle, cut short, or not there at all, the call must come back with an error -- the other
+    file's producer threads, the chunk queue and the device slots wound down -- and the engine must serve the next call."""
+    import gzip
+
+    genome = synth.make_genome(80_000, seed=61)
+    data = [synth.make_fastq(genome, 130_000, 150, seed=62 + i, device="cpu", first_index=i * 10**6).numpy().tobytes() for i in range(2)]
+    z = [bytearray(gzip.compress(d, compresslevel=3)) for d in data]
+    paths = [tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz"]
+    for i in (0, 1):
+        if which in (("first", "second")[i], "both"):
+            z[i][len(z[i]) // 2] ^= 0x41
+            z[i][len(z[i]) // 2 + 1000] ^= 0x17
+    if which == "truncated":
+        z[1] = z[1][: len(z[1]) * 2 // 3]
+    for pth, zz in zip(paths, z):
+        pth.write_bytes(bytes(zz))
+    if which == "missing":
+        paths[1].unlink()
+    if which == "truncated":
+        # a file cut short is not an error to mash: zlib hands kseq every byte it can decode, the read that fails ends
+        # the stream like an end of file, a last record without its qualities is dropped -- the sketch of the prefix
+        import zlib
+
+        prefix = zlib.decompressobj(wbits=31).decompress(bytes(z[1]))
+        assert 0 < len(prefix) < len(data[1])
+        engine.sketch_files(paths, 27, 5000, tmp_path / "x.msh", reads=True, min_mult=2)
+        ref = mo.Sketcher(27, 5000, 2)
+        ref.add_fastx(data[0])
+        ref.add_fastx(prefix)
+        assert np.array_equal(mo.read_msh(tmp_path / "x.msh").references[0].hashes, ref.finish()[0])
+    else:
+        with pytest.raises(engine.EngineError):
+            engine.sketch_files(paths, 27, 5000, tmp_path / "x.msh", reads=True, min_mult=2)
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(gzip.compress(data[0][: 3_000_000 // 315 * 315], compresslevel=3))
+    engine.sketch_files([good], 27, 5000, tmp_path / "y.msh", reads=True, min_mult=1)
+    ref = mo.Sketcher(27, 5000, 1)
+    ref.add_fastx(data[0][: 3_000_000 // 315 * 315])
+    assert np.array_equal(mo.read_msh(tmp_path / "y.msh").references[0].hashes, ref.finish()[0])
