@@ -164,6 +164,41 @@ void first_header(const uint8_t *buf, size_t n, std::string &name, std::string &
 
 // Cheap host-side plausibility test for the device FASTQ parser: starts with '@', and the
 // first record has the 4-line shape.  The device verifies every record (kFlagBadFastq).
+// Is the LAST record of a 4-line FASTQ complete in kseq's sense?  t: the last bytes of the stream.  A record that has its
+// '+' line but no quality string, or one of another length than its sequence, makes kseq_read return -2 (the oracle
+// raises "truncated quality string"): the device parser, which checks the four-line layout but not the quality lengths,
+// must not sketch such a file -- the caller hands it to the host record parser, which reports it.  A header without
+// anything behind it, or a sequence line without a '+' line, is a record to kseq (it reads it as FASTA).  true when the
+// record is complete or the tail cannot tell (no record start among its last four lines).
+bool fastq_tail_complete(const uint8_t *t, size_t n)
+{
+    size_t ls[5], le[5]; // the last (up to five) lines, newest first: [start, end) without the newline
+    int nl = 0;
+    size_t e = n;
+    if (e && t[e - 1] == '\n') --e;                 // the final newline ends the last line
+    else if (e == 0) return true;
+    while (nl < 5) {
+        size_t b = e;
+        while (b > 0 && t[b - 1] != '\n') --b;
+        ls[nl] = b; le[nl] = e; ++nl;
+        if (b == 0) break;
+        e = b - 1;
+    }
+    auto first = [&](int i) { return ls[i] < le[i] ? t[ls[i]] : (uint8_t)0; };
+    auto length = [&](int i) { size_t l = le[i] - ls[i]; if (l && t[le[i] - 1] == '\r') --l; return l; };
+    // the record start nearest to the end: a line that begins with '@', whose successor (if any) begins with neither '@'
+    // nor '+', and whose second successor (if any) begins with '+'  (index 0 = last line; successors have smaller indices)
+    for (int i = 0; i < nl && i < 4; ++i) {
+        if (first(i) != '@') continue;
+        if (i >= 1 && (first(i - 1) == '@' || first(i - 1) == '+')) continue;
+        if (i >= 2 && first(i - 2) != '+') continue;
+        if (i <= 1) return true;                                  // header only, or header + sequence: a record without qualities
+        if (i == 2) return length(1) == 0;                        // '+' line, nothing behind it
+        return length(0) == length(2);                            // i == 3: quality against sequence
+    }
+    return true;
+}
+
 bool looks_like_fastq4(const uint8_t *buf, size_t n)
 {
     if (n == 0 || buf[0] != '@') return false;
@@ -171,7 +206,9 @@ bool looks_like_fastq4(const uint8_t *buf, size_t n)
     if (!l1) return false;
     const uint8_t *l2 = (const uint8_t *)memchr(l1 + 1, '\n', n - (l1 + 1 - buf));
     if (!l2 || l2 + 1 >= buf + n) return false;
-    return l2[1] == '+';
+    if (l2[1] != '+') return false;
+    const size_t look = n < (1u << 16) ? n : (1u << 16);
+    return fastq_tail_complete(buf + n - look, look); // a last record cut short goes to the record parser, which reports it
 }
 
 // Record reader with kseq.h semantics: a record starts at '>' or '@'; name = header up to

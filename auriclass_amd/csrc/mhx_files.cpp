@@ -77,7 +77,7 @@ static int sketch_reference(const std::vector<Loaded *> &inputs, int k, uint32_t
             } else {
                 if (in->rec.records_seen == 0 && in->rec.seq.empty()) {
                     rc = parse_fastx(in->raw.data(), in->raw.size(), k, in->rec);
-                    if (rc) break;
+                    if (rc) { mhx_sketcher_destroy(sk); return rc; } // the record parser's verdict is final (not the device parser's MHX_E_FORMAT, which sends the file HERE)
                 }
                 rc = mhx_sketcher_push_host(sk, in->rec.seq.data(), in->rec.seq.size(), MHX_FMT_SEQ);
             }
@@ -557,6 +557,8 @@ void inflate_fastq(const char *path, int file, bool force_zlib, int decode_threa
             // lack its final newline)
             const uint64_t lines = count_newlines(d, n) + (n && d[n - 1] != '\n' ? 1 : 0);
             if (lines & 3) st->not_fastq4 = true;
+            const size_t look = std::min<size_t>(n, 1u << 16);
+            if (!fastq_tail_complete(d + n - look, look)) st->not_fastq4 = true; // quality string of the last record cut short: the record parser reports it
             cut = n;
         }
         if (st->not_fastq4) { close_all(); q->producer_done(); return; }
@@ -613,6 +615,7 @@ struct BulkFile {
     uint8_t *d_buf = nullptr;
     uint64_t size = 0;
     std::vector<uint8_t> head; // first bytes of the file (record name / comment)
+    std::vector<uint8_t> tail; // its last bytes (is the last record complete?)
 };
 
 static int ensure_pinned_ring()
@@ -680,6 +683,10 @@ static int bulk_load_plain(const char *path, BulkFile *f)
         if (hipEventSynchronize(g.pinned_free[slot]) != hipSuccess) { rc = fail(MHX_E_HIP, "pinned slot wait failed"); break; }
         if (!parallel_pread(fd, g.pinned[slot], off, len, len >= (8u << 20) ? nthreads : 1)) { rc = fail(MHX_E_IO, "ERROR: reading %s failed", path); break; }
         if (off == 0) f->head.assign(g.pinned[slot], g.pinned[slot] + std::min<size_t>(len, 1u << 20));
+        if (off + len >= f->size) { // the last block: keep the file's last bytes (and what the block before it contributed, if this one is short)
+            const size_t keep = std::min<size_t>(len, 1u << 16);
+            f->tail.assign(g.pinned[slot] + len - keep, g.pinned[slot] + len);
+        }
         if (hipMemcpyAsync(f->d_buf + off, g.pinned[slot], len, hipMemcpyHostToDevice, g.copy_stream) != hipSuccess ||
             hipEventRecord(g.pinned_free[slot], g.copy_stream) != hipSuccess) { rc = fail(MHX_E_HIP, "H2D copy failed"); break; }
         off += len;
@@ -765,6 +772,7 @@ static int stream_fastq_reference(const char *const *paths, int n_paths, int k, 
         if (rc) break;
         if (!bf.d_buf) { queued.push_back(i); continue; }
         if (bf.head.empty() || bf.head[0] != '@') fallback = true;
+        if (!fastq_tail_complete(bf.tail.data(), bf.tail.size())) fallback = true; // a last record without its qualities: the record parser reports it
         if (!fallback) header.offer(i, bf.head.data(), bf.head.size(), k);
         if (!fallback) rc = mhx_sketcher_push_device(sk, bf.d_buf, bf.size, MHX_FMT_FASTQ4);
         if (hipStreamSynchronize(g.stream) != hipSuccess && !rc) rc = fail(MHX_E_HIP, "stream sync failed");

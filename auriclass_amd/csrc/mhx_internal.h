@@ -49,6 +49,7 @@ bool check_ascending(const uint64_t *h, size_t n);
 
 // ---- FASTA/FASTQ ingest (mhx_fastx.cpp) -------------------------------------------------
 int read_all_maybe_gz(const char *path, std::vector<uint8_t> &out);
+bool fastq_tail_complete(const uint8_t *t, size_t n); // is the last record of a 4-line FASTQ complete in kseq's sense? (mhx_fastx.cpp)
 // Host threads the ingest may use (inflate, pread): MHX_INGEST_THREADS, else the cores this process may run on
 // (sched_getaffinity, twice the cgroup's CPU quota if it has one) divided by the ranks of this node (LOCAL_WORLD_SIZE: one
 // process per GPU), at most 32, at least 2.

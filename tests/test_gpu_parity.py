@@ -1494,3 +1494,52 @@ def test_one_bad_file_of_a_pair_ends_the_call_not_the_process(tmp_path, which):
     ref = mo.Sketcher(27, 5000, 1)
     ref.add_fastx(data[0][: 3_000_000 // 315 * 315])
     assert np.array_equal(mo.read_msh(tmp_path / "y.msh").references[0].hashes, ref.finish()[0])
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_last_record_without_its_quality_string_is_reported(tmp_path, gz):
+    """A FASTQ cut short inside its last record: with the `+` line but no qualities, or with fewer qualities than bases,
+    kseq_read answers -2 and the oracle raises -- the engine must not sketch that record's bases (its device parser checks
+    the four-line layout, not the quality lengths; the tail of every file is looked at on the host).  Cut inside the
+    header or the sequence line the record is one without qualities, which kseq returns: sketched, like the oracle does."""
+    import gzip
+
+    genome = synth.make_genome(50_000, seed=71)
+    body = synth.make_fastq(genome, 3000, 150, seed=72, device="cpu").numpy().tobytes()
+    last_seq = bytes(genome[100:250].tobytes())
+    cases = {
+        "plus_only": (b"@last\n" + last_seq + b"\n+\n", True),
+        "plus_no_newline": (b"@last\n" + last_seq + b"\n+", True),
+        "short_quality": (b"@last\n" + last_seq + b"\n+\n" + b"I" * 100 + b"\n", True),
+        "short_quality_no_newline": (b"@last\n" + last_seq + b"\n+\n" + b"I" * 149, True),
+        "long_quality": (b"@last\n" + last_seq + b"\n+\n" + b"I" * 151 + b"\n", True),
+        "cut_in_sequence": (b"@last\n" + last_seq[:77], False),
+        "cut_after_sequence": (b"@last\n" + last_seq + b"\n", False),
+        "header_only": (b"@last\n", False),
+        "complete_no_newline": (b"@last\n" + last_seq + b"\n+\n" + b"I" * 150, False),
+        "complete_crlf": (b"@last\r\n" + last_seq + b"\r\n+\r\n" + b"I" * 150 + b"\r\n", False),
+    }
+    for name, (tail, bad) in cases.items():
+        for lead in (body, b""):
+            data = lead + tail
+            p = tmp_path / (name + (".fq.gz" if gz else ".fq"))
+            p.write_bytes(gzip.compress(data, 3) if gz else data)
+            ref = mo.Sketcher(21, 1000, 1)
+            try:
+                ref.add_fastx(data)
+                oracle_raises = False
+            except ValueError:
+                oracle_raises = True
+            assert oracle_raises == bad, name
+            if bad:
+                with pytest.raises(engine.EngineError):
+                    engine.sketch_files([p], 21, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
+                    print("NOT REFUSED:", name, len(lead), "gz" if gz else "plain")
+                continue
+            want = ref.finish()[0]
+            if len(want) == 0:   # nothing of k bases: "Did not find fasta records"
+                with pytest.raises(engine.EngineError):
+                    engine.sketch_files([p], 21, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
+                continue
+            engine.sketch_files([p], 21, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
+            assert np.array_equal(mo.read_msh(tmp_path / "o.msh").references[0].hashes, want), (name, len(lead))

@@ -415,3 +415,25 @@ def test_whole_file_reader_on_concatenated_members_longer_than_the_last_one_anno
         p.write_bytes(b"".join(gzip.compress(x, compresslevel=4) for x in parts))
         assert engine.fasta_total_bases(p) == 9000 * sum(sizes)
         assert engine.sniff_fasta(p) and not engine.sniff_fastq(p)
+
+
+def test_fastq_tail_completeness_rule(lib):
+    """The host's look at the end of a 4-line FASTQ stream (`fastq_tail_complete`, mhx_fastx.cpp): a last record with its
+    `+` line but no, too short or too long a quality string is incomplete (kseq_read: -2); a header alone, a record cut in
+    its sequence line, a complete record with or without its final newline, with CRLF, are records."""
+    f = getattr(lib, "_ZN3mhx19fastq_tail_completeEPKhm")
+    f.restype = ctypes.c_bool
+    f.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    seq = b"ACGT" * 37 + b"AC"
+    body = b"@r1 x\n" + seq + b"\n+\n" + b"@" * 150 + b"\n"      # (a quality line that begins with '@')
+    cases = {
+        b"@l\n" + seq + b"\n+\n": False, b"@l\n" + seq + b"\n+": False, b"@l\n" + seq + b"\n+l\n" + b"I" * 100 + b"\n": False,
+        b"@l\n" + seq + b"\n+\n" + b"I" * 149: False, b"@l\n" + seq + b"\n+\n" + b"I" * 151 + b"\n": False,
+        b"@l\n" + seq[:77]: True, b"@l\n" + seq + b"\n": True, b"@l\n": True, b"@l": True, b"": True,
+        b"@l\n" + seq + b"\n+\n" + b"I" * 150: True, b"@l\r\n" + seq + b"\r\n+\r\n" + b"I" * 150 + b"\r\n": True,
+        b"@l\n" + seq + b"\n+\n" + b"@" * 150 + b"\n": True, b"@l\n\n+\n\n": True, b"@l\n\n+\n": True,
+    }
+    for tail, want in cases.items():
+        for lead in (body, b"", body * 3):
+            data = lead + tail
+            assert f(data, len(data)) == want, (tail[:20], len(lead))
