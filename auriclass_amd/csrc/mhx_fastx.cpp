@@ -327,6 +327,7 @@ static int sniff_guarded(const char *path, char lead)
 }
 extern "C" int mhx_sniff_fastq(const char *path) { return sniff_guarded(path, '@'); }
 extern "C" int mhx_sniff_fasta(const char *path) { return sniff_guarded(path, '>'); }
+extern "C" int mhx_fastq_tail_complete(const void *tail, size_t n) { return tail || n == 0 ? (fastq_tail_complete((const uint8_t *)tail, n) ? 1 : 0) : 1; }
 
 static int fasta_total_bases_impl(const char *path, uint64_t *total)
 {

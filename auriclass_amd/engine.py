@@ -84,6 +84,8 @@ def load() -> ctypes.CDLL:
     L.mhx_fasta_total_bases.argtypes = [c.c_char_p, u64p]
     L.mhx_sniff_fastq.argtypes = [c.c_char_p]
     L.mhx_sniff_fasta.argtypes = [c.c_char_p]
+    L.mhx_fastq_tail_complete.argtypes = [c.c_char_p, c.c_size_t]
+    L.mhx_fastq_tail_complete.restype = c.c_int
     L.mhx_sketcher_create.argtypes = [c.c_int, c.c_uint32, c.c_uint32, c.c_uint64, c.POINTER(c.c_void_p)]
     L.mhx_sketcher_create_scaled.argtypes = [c.c_int, c.c_uint32, c.c_uint32, c.c_uint64, c.c_uint32, c.POINTER(c.c_void_p)]
     L.mhx_sketcher_destroy.argtypes = [c.c_void_p]
@@ -203,6 +205,11 @@ def fasta_total_bases(path) -> int:
     v = ctypes.c_uint64(0)
     _check(load().mhx_fasta_total_bases(os.fsencode(str(path)), ctypes.byref(v)))
     return v.value
+
+
+def fastq_tail_complete(tail: bytes) -> bool:
+    """Is the last record of a 4-line FASTQ complete (its last bytes are enough)?  See mhx_fastq_tail_complete."""
+    return bool(load().mhx_fastq_tail_complete(tail, len(tail)))
 
 
 def sniff_fastq(path) -> bool:

@@ -402,8 +402,12 @@ def sketch_fastq_files(paths, k: int, s: int, min_mult: int, out_msh, device: to
             if i % world == rank:
                 with open(p, "rb") as fh:
                     pieces.append(np.frombuffer(engine.gunzip(fh.read(), threads=8), dtype=np.uint8))
+                    if not engine.fastq_tail_complete(pieces[-1][-65536:].tobytes()):
+                        raise engine.EngineError(engine.MHX_E_FORMAT, f"truncated quality string in the last FASTQ record of {p}")
         else:
             mm = np.memmap(p, dtype=np.uint8, mode="r")
+            if not engine.fastq_tail_complete(bytes(mm[max(0, len(mm) - 65536):])):   # every rank looks: all raise together
+                raise engine.EngineError(engine.MHX_E_FORMAT, f"truncated quality string in the last FASTQ record of {p}")
             cuts = fastq_record_cuts(mm, world)
             if cuts[rank + 1] > cuts[rank]:
                 pieces.append(mm[cuts[rank]:cuts[rank + 1]])

@@ -82,6 +82,10 @@ int mhx_fasta_total_bases(const char *path, uint64_t *total);
 /* format sniffing (replaces pyfastx probes, general.py:68-115): 1 yes, 0 no, <0 error */
 int mhx_sniff_fastq(const char *path);
 int mhx_sniff_fasta(const char *path);
+/* the end of a 4-line FASTQ stream (its last bytes, up to 64 KiB are enough): 1 when the last record is complete in kseq's
+ * sense, 0 when it has its '+' line but no, or a differently long, quality string (kseq_read: -2; such a file is refused
+ * by mhx_sketch_files); callers that push byte ranges of a file themselves ask here for its tail */
+int mhx_fastq_tail_complete(const void *tail, size_t n);
 
 /* ---- buffer level: the hot path itself ------------------------------------------------ */
 typedef struct mhx_sketcher mhx_sketcher;

@@ -466,3 +466,33 @@ def test_fewer_records_than_ranks(tmp_path, form, m):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), want), f"rank {r}"
         assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), wc), f"rank {r}"
+
+
+def _files_error_worker(rank, world, port, paths, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auriclass_amd import engine
+
+    engine.init(0)
+    try:
+        multigpu.sketch_fastq_files(paths, 21, 1000, 1, os.path.join(out_dir, "x.msh"), torch.device("cpu"))
+        verdict = "sketched"
+    except engine.EngineError as e:
+        verdict = "refused: " + e.message
+    with open(os.path.join(out_dir, f"v{rank}.txt"), "w") as fh:
+        fh.write(verdict)
+    dist.destroy_process_group()
+
+
+def test_sharded_file_level_sketch_refuses_a_last_record_without_qualities(tmp_path):
+    """The sharded form pushes byte ranges of a file itself: it asks the library about the file's tail
+    (mhx_fastq_tail_complete) and every rank refuses a FASTQ cut short inside its last record, like the one-GPU call."""
+    data = _ragged_input()
+    cut = data.rindex(b"\n+\n") + 3           # the last record keeps its '+' line and loses its qualities
+    p = tmp_path / "cut.fq"
+    p.write_bytes(data[:cut])
+    mp.spawn(_files_error_worker, args=(2, _free_port(), [str(p)], str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"v{r}.txt").read_text().startswith("refused: truncated quality string"), r

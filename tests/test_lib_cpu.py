@@ -421,9 +421,9 @@ def test_fastq_tail_completeness_rule(lib):
     """The host's look at the end of a 4-line FASTQ stream (`fastq_tail_complete`, mhx_fastx.cpp): a last record with its
     `+` line but no, too short or too long a quality string is incomplete (kseq_read: -2); a header alone, a record cut in
     its sequence line, a complete record with or without its final newline, with CRLF, are records."""
-    f = getattr(lib, "_ZN3mhx19fastq_tail_completeEPKhm")
-    f.restype = ctypes.c_bool
-    f.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    def f(data, n):
+        return engine.fastq_tail_complete(data[:n])
+
     seq = b"ACGT" * 37 + b"AC"
     body = b"@r1 x\n" + seq + b"\n+\n" + b"@" * 150 + b"\n"      # (a quality line that begins with '@')
     cases = {
