@@ -1543,3 +1543,37 @@ def test_last_record_without_its_quality_string_is_reported(tmp_path, gz):
                 continue
             engine.sketch_files([p], 21, 1000, tmp_path / "o.msh", reads=True, min_mult=1)
             assert np.array_equal(mo.read_msh(tmp_path / "o.msh").references[0].hashes, want), (name, len(lead))
+
+
+def test_damaged_sketch_containers_end_in_an_error_or_a_table_never_in_a_crash(tmp_path):
+    """`mash dist` on `.msh` files cut short or with bytes flipped (header and pointer area, anywhere): the reference's own
+    fixture (the copying reader) and a 9.6 MB container (the pinned image, parsed in place).  Every call must come back --
+    with an error, or with a table when the damage left the structure valid (flipped hash or name bytes) -- and the engine
+    must answer the undamaged question afterwards."""
+    rng = np.random.default_rng(12)
+    small = (REFDATA / "ref_sketch.msh").read_bytes()
+    refs = [mo.Reference("r%d" % j, "c", 10 ** 7, _sketch_like(rng, 40000)) for j in range(30)]
+    big = mo.msh_bytes(mo.SketchFile(kmer_size=27, sketch_size=40000, references=refs))
+    (tmp_path / "q.msh").write_bytes(small)
+    (tmp_path / "qb.msh").write_bytes(mo.msh_bytes(mo.SketchFile(kmer_size=27, sketch_size=40000, references=refs[:1])))
+    (tmp_path / "big.msh").write_bytes(big)
+    good = {"small": engine.dist_files(tmp_path / "q.msh", tmp_path / "q.msh"), "big": engine.dist_files(tmp_path / "big.msh", tmp_path / "qb.msh")}
+    outcomes = {"error": 0, "table": 0}
+    for name, blob, query in (("small", small, "q.msh"), ("big", big, "qb.msh")):
+        for trial in range(45 * FUZZ):
+            b = bytearray(blob)
+            if trial % 3 == 0:
+                b = b[: int(rng.integers(0, len(b)))]
+            else:
+                span = min(len(b), 4096) if trial % 3 == 1 else len(b)
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, span))] ^= int(rng.integers(1, 256))
+            (tmp_path / "m.msh").write_bytes(bytes(b))
+            try:
+                engine.dist_files(tmp_path / "m.msh", tmp_path / query)
+                outcomes["table"] += 1
+            except engine.EngineError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0
+    assert engine.dist_files(tmp_path / "q.msh", tmp_path / "q.msh") == good["small"]
+    assert engine.dist_files(tmp_path / "big.msh", tmp_path / "qb.msh") == good["big"]
